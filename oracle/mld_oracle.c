@@ -1,0 +1,787 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.  Never linked into, called from, or shipped with the product
+ * path (pyhybridcontrol_amd/).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library.
+ *
+ * Plain-C fp64 CPU restatement of the MPC hot path of michchr/pyhybridcontrol:
+ *   (1) condensing an MLD model over the horizon
+ *         controllers/components/mld_evolution_matrices.py:137-244, 253-332, 467-527
+ *         utils/matrix_utils.py:55-81, 117-161
+ *   (2) the constraint right-hand side  h = H_x x_k + H_omega omega + H_5
+ *         controllers/controller_base.py:446-450
+ *   (3) the mixed-integer solve the reference delegates to cvxpy -> Gurobi
+ *         controllers/controller_base.py:509 ; variable layout controllers/components/variables.py:189-243
+ *       Gurobi is third-party, proprietary, un-pinned and absent from /root/reference; what is
+ *       restated here is the published textbook algorithm: bounded dual simplex on a dense
+ *       dictionary with a Harris ratio test (Chvatal 1983; Harris 1973), Gomory mixed-integer cut
+ *       rounds at the root (Gomory 1960; Balas/Ceria/Cornuejols/Natraj 1996), row-activity bound
+ *       propagation (Savelsbergh 1994) and depth-first LP-based branch-and-bound (Land/Doig 1960).
+ *
+ * Pinning: (1),(2) against golden vectors produced by the reference itself (tests/golden/, made by
+ * oracle/gen_golden.py); (3) has no reference fixture (the reference has no tests) -> "parity
+ * unpinned" at the solver boundary; it is cross-checked against exhaustive enumeration and
+ * scipy.optimize.milp (HiGHS) in tests/test_oracle_solver.py.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_BIG 1.0e7
+#define ORC_PTOL 1e-8
+#define ORC_PTOL_SKIP 1e-6
+#define ORC_DTOL 1e-9
+#define ORC_PIV_ABS 1e-7
+#define ORC_PIV_REL 1e-7
+#define ORC_INTTOL 1e-6
+#define ORC_COEF_ZERO 1e-9
+#define ORC_RESID_TOL 1e-6
+
+enum { ORC_OPTIMAL = 0, ORC_INFEASIBLE = 1, ORC_NODE_LIMIT = 2, ORC_NUMERICAL = 3 };
+enum { LP_OPTIMAL = 0, LP_INFEASIBLE = 1, LP_CUTOFF = 2, LP_ITERLIMIT = 3 };
+
+typedef struct {
+    int nx, nu, ndelta, nz, nmu, nomega, ny, nc, nu_l, nmu_l;
+} orc_dims;
+
+typedef struct {
+    double gap_abs, gap_rel;
+    int max_nodes, cut_rounds, cuts_per_round, max_cuts, max_pivots, presolve;
+} orc_opts;
+
+typedef struct {
+    int nodes, pivots, cuts, refactors, status;
+    double root_lp, root_bound, lower_bound;
+} orc_stats;
+
+/* ------------------------------------------------------------------------------------------------
+ * (1) condensing.  All matrices row-major.  Outputs may be NULL.  v = [u; delta; z; mu] per step.
+ * ---------------------------------------------------------------------------------------------- */
+static void matmul_acc(double *C, const double *A, const double *B, int m, int k, int n, int ldc, double alpha)
+{ /* C[m x n] (ld ldc) += alpha * A[m x k] * B[k x n] */
+    for (int i = 0; i < m; ++i)
+        for (int p = 0; p < k; ++p) {
+            double a = alpha * A[i * k + p];
+            if (a == 0.0) continue;
+            for (int j = 0; j < n; ++j) C[i * ldc + j] += a * B[p * n + j];
+        }
+}
+
+int orc_condense(const orc_dims *d, int N, const double *A, const double *B1, const double *B2, const double *B3,
+                 const double *B4, const double *b5, const double *C, const double *D1, const double *D2,
+                 const double *D3, const double *D4, const double *d5, const double *E, const double *F1,
+                 const double *F2, const double *F3, const double *F4, const double *f5, const double *G,
+                 const double *Psi, double *Phi_x, double *Gamma_v, double *Gamma_w, double *Gamma_5, double *L_x,
+                 double *L_v, double *L_w, double *L_5, double *H_x, double *H_v, double *H_w, double *H_5)
+{
+    const int nx = d->nx, nu = d->nu, nd = d->ndelta, nz = d->nz, nmu = d->nmu, nw = d->nomega, ny = d->ny,
+              nc = d->nc;
+    const int nv = nu + nd + nz + nmu;
+    /* hstacks  Bv=[B1 B2 B3 0], Dv=[D1 D2 D3 0], Fv=[F1 F2 F3 Psi]  (mld_evolution_matrices.py:291,355,411) */
+    double *Bv = calloc((size_t)nx * nv + 1, sizeof(double)), *Dv = calloc((size_t)ny * nv + 1, sizeof(double)),
+           *Fv = calloc((size_t)nc * nv + 1, sizeof(double));
+    for (int i = 0; i < nx; ++i) {
+        for (int j = 0; j < nu; ++j) Bv[i * nv + j] = B1 ? B1[i * nu + j] : 0;
+        for (int j = 0; j < nd; ++j) Bv[i * nv + nu + j] = B2 ? B2[i * nd + j] : 0;
+        for (int j = 0; j < nz; ++j) Bv[i * nv + nu + nd + j] = B3 ? B3[i * nz + j] : 0;
+    }
+    for (int i = 0; i < ny; ++i) {
+        for (int j = 0; j < nu; ++j) Dv[i * nv + j] = D1 ? D1[i * nu + j] : 0;
+        for (int j = 0; j < nd; ++j) Dv[i * nv + nu + j] = D2 ? D2[i * nd + j] : 0;
+        for (int j = 0; j < nz; ++j) Dv[i * nv + nu + nd + j] = D3 ? D3[i * nz + j] : 0;
+    }
+    for (int i = 0; i < nc; ++i) {
+        for (int j = 0; j < nu; ++j) Fv[i * nv + j] = F1 ? F1[i * nu + j] : 0;
+        for (int j = 0; j < nd; ++j) Fv[i * nv + nu + j] = F2 ? F2[i * nd + j] : 0;
+        for (int j = 0; j < nz; ++j) Fv[i * nv + nu + nd + j] = F3 ? F3[i * nz + j] : 0;
+        for (int j = 0; j < nmu; ++j) Fv[i * nv + nu + nd + nz + j] = Psi ? Psi[i * nmu + j] : 0;
+    }
+    /* per-lag blocks: Ak = A^k ; ABv[k] = A^k Bv ; ABw[k] = A^k B4 ; Ab5[k] = A^k b5 ; S5[k]=sum_{j<k} A^j b5 */
+    double *Ak = calloc((size_t)N * nx * nx + 1, sizeof(double));
+    double *ABv = calloc((size_t)N * nx * nv + 1, sizeof(double));
+    double *ABw = calloc((size_t)N * nx * nw + 1, sizeof(double));
+    double *S5 = calloc((size_t)(N + 1) * nx + 1, sizeof(double));
+    for (int i = 0; i < nx; ++i) Ak[i * nx + i] = 1.0;
+    for (int k = 1; k < N; ++k) /* A^k = A^{k-1} A   (mld_evolution_matrices.py:272 accumulate x@y) */
+        if (A) matmul_acc(Ak + (size_t)k * nx * nx, Ak + (size_t)(k - 1) * nx * nx, A, nx, nx, nx, nx, 1.0);
+    for (int k = 0; k < N; ++k) {
+        matmul_acc(ABv + (size_t)k * nx * nv, Ak + (size_t)k * nx * nx, Bv, nx, nx, nv, nv, 1.0);
+        if (B4) matmul_acc(ABw + (size_t)k * nx * nw, Ak + (size_t)k * nx * nx, B4, nx, nx, nw, nw, 1.0);
+        /* Gamma_5 block row k = sum_{j=0}^{k-1} A^j b5  (toeplitz([0,A^0 b5,...]) @ ones, :331-332) */
+        for (int i = 0; i < nx; ++i) S5[(k + 1) * nx + i] = S5[k * nx + i];
+        if (b5) matmul_acc(S5 + (size_t)(k + 1) * nx, Ak + (size_t)k * nx * nx, b5, nx, nx, 1, 1, 1.0);
+    }
+    const int n = N * nv, nW = N * nw;
+    /* state maps */
+    if (Phi_x) memcpy(Phi_x, Ak, sizeof(double) * (size_t)N * nx * nx);
+    if (Gamma_v) memset(Gamma_v, 0, sizeof(double) * (size_t)N * nx * n);
+    if (Gamma_w) memset(Gamma_w, 0, sizeof(double) * (size_t)N * nx * nW);
+    for (int i = 1; i < N; ++i)
+        for (int j = 0; j < i; ++j) { /* block (i,j) = A^{i-j-1} B */
+            const int lag = i - j - 1;
+            if (Gamma_v)
+                for (int r = 0; r < nx; ++r)
+                    memcpy(Gamma_v + ((size_t)(i * nx + r)) * n + j * nv, ABv + ((size_t)lag * nx + r) * nv,
+                           sizeof(double) * nv);
+            if (Gamma_w)
+                for (int r = 0; r < nx; ++r)
+                    memcpy(Gamma_w + ((size_t)(i * nx + r)) * nW + j * nw, ABw + ((size_t)lag * nx + r) * nw,
+                           sizeof(double) * nw);
+        }
+    if (Gamma_5)
+        for (int k = 0; k < N; ++k)
+            for (int r = 0; r < nx; ++r) Gamma_5[k * nx + r] = S5[k * nx + r];
+    /* output and constraint maps, block by block:
+     *   L(i,j)  = C Gamma(i,j) + [i==j] Dv           (:186-189)
+     *   H_v(i,j)= E Gamma(i,j) + [i==j] Fv + G L(i,j) (:237-240)  etc. */
+    double *Lb = calloc((size_t)ny * (nv + nw + nx + 1) + 1, sizeof(double));
+    double *Hb = calloc((size_t)nc * (nv + nw + nx + 1) + 1, sizeof(double));
+    if (L_v) memset(L_v, 0, sizeof(double) * (size_t)N * ny * n);
+    if (L_w) memset(L_w, 0, sizeof(double) * (size_t)N * ny * nW);
+    if (H_v) memset(H_v, 0, sizeof(double) * (size_t)N * nc * n);
+    if (H_w) memset(H_w, 0, sizeof(double) * (size_t)N * nc * nW);
+    for (int lag = -1; lag < N - 1; ++lag) { /* lag=-1 is the diagonal block (Gamma block = 0) */
+        /* v part */
+        memset(Lb, 0, sizeof(double) * (size_t)ny * nv);
+        memset(Hb, 0, sizeof(double) * (size_t)nc * nv);
+        if (lag >= 0) {
+            if (C) matmul_acc(Lb, C, ABv + (size_t)lag * nx * nv, ny, nx, nv, nv, 1.0);
+            if (E) matmul_acc(Hb, E, ABv + (size_t)lag * nx * nv, nc, nx, nv, nv, 1.0);
+        } else {
+            for (int t = 0; t < ny * nv; ++t) Lb[t] += Dv[t];
+            for (int t = 0; t < nc * nv; ++t) Hb[t] += Fv[t];
+        }
+        if (G) matmul_acc(Hb, G, Lb, nc, ny, nv, nv, 1.0);
+        for (int i = lag + 1; i < N; ++i) {
+            const int j = i - lag - 1;
+            if (L_v)
+                for (int r = 0; r < ny; ++r)
+                    memcpy(L_v + ((size_t)(i * ny + r)) * n + j * nv, Lb + (size_t)r * nv, sizeof(double) * nv);
+            if (H_v)
+                for (int r = 0; r < nc; ++r)
+                    memcpy(H_v + ((size_t)(i * nc + r)) * n + j * nv, Hb + (size_t)r * nv, sizeof(double) * nv);
+        }
+        /* omega part (sign flipped for H, :239) */
+        memset(Lb, 0, sizeof(double) * (size_t)ny * nw);
+        memset(Hb, 0, sizeof(double) * (size_t)nc * nw);
+        if (lag >= 0) {
+            if (C) matmul_acc(Lb, C, ABw + (size_t)lag * nx * nw, ny, nx, nw, nw, 1.0);
+            if (E) matmul_acc(Hb, E, ABw + (size_t)lag * nx * nw, nc, nx, nw, nw, 1.0);
+        } else {
+            if (D4) for (int t = 0; t < ny * nw; ++t) Lb[t] += D4[t];
+            if (F4) for (int t = 0; t < nc * nw; ++t) Hb[t] += F4[t];
+        }
+        if (G) matmul_acc(Hb, G, Lb, nc, ny, nw, nw, 1.0);
+        for (int i = lag + 1; i < N; ++i) {
+            const int j = i - lag - 1;
+            if (L_w)
+                for (int r = 0; r < ny; ++r)
+                    memcpy(L_w + ((size_t)(i * ny + r)) * nW + j * nw, Lb + (size_t)r * nw, sizeof(double) * nw);
+            if (H_w)
+                for (int r = 0; r < nc; ++r)
+                    for (int c = 0; c < nw; ++c) H_w[((size_t)(i * nc + r)) * nW + j * nw + c] = -Hb[(size_t)r * nw + c];
+        }
+    }
+    /* x and constant columns, one block row at a time */
+    for (int k = 0; k < N; ++k) {
+        memset(Lb, 0, sizeof(double) * (size_t)ny * (nx + 1));
+        memset(Hb, 0, sizeof(double) * (size_t)nc * (nx + 1));
+        if (C) matmul_acc(Lb, C, Ak + (size_t)k * nx * nx, ny, nx, nx, nx, 1.0); /* L_x = C A^k */
+        if (E) matmul_acc(Hb, E, Ak + (size_t)k * nx * nx, nc, nx, nx, nx, 1.0);
+        if (G) matmul_acc(Hb, G, Lb, nc, ny, nx, nx, 1.0);
+        for (int r = 0; r < ny && L_x; ++r) memcpy(L_x + ((size_t)(k * ny + r)) * nx, Lb + (size_t)r * nx, sizeof(double) * nx);
+        for (int r = 0; r < nc && H_x; ++r)
+            for (int c = 0; c < nx; ++c) H_x[((size_t)(k * nc + r)) * nx + c] = -Hb[(size_t)r * nx + c];
+        double *l5 = Lb + (size_t)ny * nx, *h5 = Hb + (size_t)nc * nx;
+        for (int r = 0; r < ny; ++r) l5[r] = d5 ? d5[r] : 0.0;
+        if (C) matmul_acc(l5, C, S5 + (size_t)k * nx, ny, nx, 1, 1, 1.0);
+        for (int r = 0; r < nc; ++r) h5[r] = 0.0;
+        if (E) matmul_acc(h5, E, S5 + (size_t)k * nx, nc, nx, 1, 1, 1.0);
+        if (G) matmul_acc(h5, G, l5, nc, ny, 1, 1, 1.0);
+        for (int r = 0; r < ny && L_5; ++r) L_5[k * ny + r] = l5[r];
+        for (int r = 0; r < nc && H_5; ++r) H_5[k * nc + r] = (f5 ? f5[r] : 0.0) - h5[r];
+    }
+    free(Bv); free(Dv); free(Fv); free(Ak); free(ABv); free(ABw); free(S5); free(Lb); free(Hb);
+    return 0;
+}
+
+/* (2)  h = H_x x0 + H_w w + H_5  (controller_base.py:446-450) */
+void orc_rhs(int m, int nx, int nW, const double *H_x, const double *H_w, const double *H_5, const double *x0,
+             const double *w, double *h)
+{
+    for (int i = 0; i < m; ++i) {
+        double s = H_5[i];
+        for (int j = 0; j < nx; ++j) s += H_x[(size_t)i * nx + j] * x0[j];
+        for (int j = 0; j < nW; ++j) s += H_w[(size_t)i * nW + j] * w[j];
+        h[i] = s;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * (3) MILP by cut-and-branch on one dense dictionary.
+ *     xB[r] = D[r][n] - sum_c D[r][c] xN[c]   (column n holds beta);  row mcap is the cost row.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int n, m0, m, mcap, ld, ntot;
+    double *D;          /* (mcap+1) x ld ; row mcap = reduced costs d (col n = z0) */
+    double *Gx, *hx;    /* scaled original rows + cuts: mcap x n, mcap */
+    double *q, *rs, *cs;
+    double *lo, *hi;    /* ntot */
+    double *xB, *xN;
+    int *basic, *nonbasic, *where; /* where[id] = column index if nonbasic else -1-row */
+    unsigned char *at_upper, *is_int, *skip;
+    long pivots, max_pivots;
+    int refactors;
+    double *tmp_col, *tmp_row;
+} dict_t;
+
+static double *dalloc(size_t k) { return (double *)calloc(k + 1, sizeof(double)); }
+
+static void equilibrate(const double *G, int m, int n, const unsigned char *is_int, double *rs, double *cs)
+{
+    for (int i = 0; i < m; ++i) rs[i] = 1.0;
+    for (int j = 0; j < n; ++j) cs[j] = 1.0;
+    double *cmax = dalloc(n);
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int i = 0; i < m; ++i) {
+            double mx = 0;
+            for (int j = 0; j < n; ++j) { double a = fabs(G[(size_t)i * n + j]) * rs[i] * cs[j]; if (a > mx) mx = a; }
+            if (mx > 0) rs[i] /= mx;
+        }
+        for (int j = 0; j < n; ++j) cmax[j] = 0;
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < n; ++j) { double a = fabs(G[(size_t)i * n + j]) * rs[i] * cs[j]; if (a > cmax[j]) cmax[j] = a; }
+        for (int j = 0; j < n; ++j) if (!is_int[j] && cmax[j] > 0) cs[j] /= cmax[j];
+    }
+    for (int i = 0; i < m; ++i) rs[i] = exp2(rint(log2(rs[i])));
+    for (int j = 0; j < n; ++j) cs[j] = exp2(rint(log2(cs[j])));
+    free(cmax);
+}
+
+static void reset_dictionary(dict_t *t)
+{
+    const int n = t->n, ld = t->ld;
+    for (int i = 0; i < t->mcap; ++i) {
+        memcpy(t->D + (size_t)i * ld, t->Gx + (size_t)i * n, sizeof(double) * n);
+        t->D[(size_t)i * ld + n] = t->hx[i];
+    }
+    memcpy(t->D + (size_t)t->mcap * ld, t->q, sizeof(double) * n);
+    t->D[(size_t)t->mcap * ld + n] = 0.0;
+    for (int i = 0; i < t->mcap; ++i) { t->basic[i] = n + i; t->where[n + i] = -1 - i; }
+    for (int j = 0; j < n; ++j) { t->nonbasic[j] = j; t->where[j] = j; }
+}
+
+static void refresh(dict_t *t)
+{
+    const int n = t->n, ld = t->ld;
+    for (int r = 0; r < t->m; ++r) {
+        const double *row = t->D + (size_t)r * ld;
+        double s = row[n];
+        for (int c = 0; c < n; ++c) s -= row[c] * t->xN[c];
+        t->xB[r] = s;
+    }
+}
+
+static double objective(const dict_t *t)
+{
+    const double *d = t->D + (size_t)t->mcap * t->ld;
+    double s = d[t->n];
+    for (int c = 0; c < t->n; ++c) s += d[c] * t->xN[c];
+    return s;
+}
+
+static void place(dict_t *t, int c)
+{
+    const int j = t->nonbasic[c];
+    const double dc = t->D[(size_t)t->mcap * t->ld + c];
+    if (t->lo[j] == t->hi[j]) { t->at_upper[c] = 0; t->xN[c] = t->lo[j]; }
+    else if (dc >= 0) { if (!isfinite(t->lo[j])) t->lo[j] = -ORC_BIG; t->at_upper[c] = 0; t->xN[c] = t->lo[j]; }
+    else { if (!isfinite(t->hi[j])) t->hi[j] = ORC_BIG; t->at_upper[c] = 1; t->xN[c] = t->hi[j]; }
+}
+
+static void set_bounds(dict_t *t, int j, double lo, double hi)
+{
+    t->lo[j] = lo; t->hi[j] = hi;
+    const int c = t->where[j];
+    if (c < 0) return;
+    const double old = t->xN[c];
+    const double dc = t->D[(size_t)t->mcap * t->ld + c];
+    double nw;
+    if (lo == hi) { nw = lo; t->at_upper[c] = 0; }
+    else if (dc >= 0) { nw = lo; t->at_upper[c] = 0; }
+    else { nw = hi; t->at_upper[c] = 1; }
+    if (nw != old) {
+        const double dl = nw - old;
+        for (int r = 0; r < t->m; ++r) t->xB[r] -= t->D[(size_t)r * t->ld + c] * dl;
+        t->xN[c] = nw;
+    }
+}
+
+static void pivot(dict_t *t, int r, int c, double leave_value)
+{
+    const int n = t->n, ld = t->ld, m = t->m;
+    double *D = t->D;
+    double *rowr = D + (size_t)r * ld;
+    const double p = rowr[c];
+    const double theta = (t->xB[r] - leave_value) / p;
+    double *colc = t->tmp_col;
+    for (int i = 0; i < m; ++i) colc[i] = D[(size_t)i * ld + c];
+    for (int i = 0; i < m; ++i) t->xB[i] -= colc[i] * theta;
+    const double enter_val = t->xN[c] + theta;
+    const double inv = 1.0 / p;
+    for (int k = 0; k <= n; ++k) rowr[k] *= inv;
+    rowr[c] = inv;
+    colc[r] = 0.0;
+    for (int i = 0; i < m; ++i) {
+        if (i == r) continue;
+        const double mu = colc[i];
+        if (mu == 0.0) continue;
+        double *ri = D + (size_t)i * ld;
+        for (int k = 0; k <= n; ++k) ri[k] -= mu * rowr[k];
+        ri[c] = -mu * inv;
+    }
+    { /* cost row: obj = d[n] + sum_c d_c xN_c ; substituting xN_c = rowr[n] - sum_k rowr[k] xN_k */
+        double *d = D + (size_t)t->mcap * ld;
+        const double dc = d[c];
+        if (dc != 0.0) {
+            for (int k = 0; k < n; ++k) d[k] -= dc * rowr[k];
+            d[c] = -dc * inv;
+            d[n] += dc * rowr[n];
+        }
+    }
+    const int jb = t->basic[r], jn = t->nonbasic[c];
+    t->basic[r] = jn; t->nonbasic[c] = jb;
+    t->where[jn] = -1 - r; t->where[jb] = c;
+    t->xB[r] = enter_val;
+    t->xN[c] = leave_value;
+    t->at_upper[c] = (leave_value == t->hi[jb]) && (t->lo[jb] != t->hi[jb]);
+    t->pivots++;
+}
+
+static double check_residual(const dict_t *t)
+{
+    const int n = t->n;
+    double *x = t->tmp_row;
+    for (int c = 0; c < n; ++c) if (t->nonbasic[c] < n) x[t->nonbasic[c]] = t->xN[c];
+    for (int r = 0; r < t->m; ++r) if (t->basic[r] < n) x[t->basic[r]] = t->xB[r];
+    double worst = 0;
+    for (int i = 0; i < t->m; ++i) {
+        const double *g = t->Gx + (size_t)i * n;
+        double s = t->hx[i];
+        for (int j = 0; j < n; ++j) s -= g[j] * x[j];
+        const int w = t->where[n + i];
+        const double v = (w >= 0) ? t->xN[w] : t->xB[-1 - w];
+        const double e = fabs(s - v);
+        if (e > worst) worst = e;
+    }
+    return worst;
+}
+
+static void refactor(dict_t *t)
+{
+    const int n = t->n, m = t->m, ld = t->ld;
+    t->refactors++;
+    unsigned char *want = (unsigned char *)calloc(n + 1, 1);       /* structurals that must be basic */
+    unsigned char *rowfree = (unsigned char *)calloc(m + 1, 1);    /* slacks that must be nonbasic */
+    double *val = dalloc(t->ntot);
+    unsigned char *up = (unsigned char *)calloc(t->ntot + 1, 1);
+    int nwant = 0;
+    for (int r = 0; r < m; ++r) if (t->basic[r] < n) { want[t->basic[r]] = 1; nwant++; }
+    for (int c = 0; c < n; ++c) {
+        const int j = t->nonbasic[c];
+        val[j] = t->xN[c]; up[j] = t->at_upper[c];
+        if (j >= n) rowfree[j - n] = 1;
+    }
+    reset_dictionary(t);
+    for (int c = 0; c < n; ++c) t->xN[c] = 0;
+    for (int r = 0; r < m; ++r) t->xB[r] = 0;
+    const long saved = t->pivots;
+    for (int k = 0; k < nwant; ++k) {
+        double best = -1; int br = -1, bc = -1;
+        for (int r = 0; r < m; ++r) {
+            if (!rowfree[r]) continue;
+            const double *row = t->D + (size_t)r * ld;
+            for (int c = 0; c < n; ++c)
+                if (want[c] && t->nonbasic[c] == c && fabs(row[c]) > best) { best = fabs(row[c]); br = r; bc = c; }
+        }
+        if (br < 0 || best <= 0) break;
+        pivot(t, br, bc, 0.0);
+        rowfree[br] = 0; want[bc] = 0;
+    }
+    t->pivots = saved;
+    for (int c = 0; c < n; ++c) { const int j = t->nonbasic[c]; t->xN[c] = val[j]; t->at_upper[c] = up[j]; }
+    refresh(t);
+    free(want); free(rowfree); free(val); free(up);
+}
+
+static int dual_simplex(dict_t *t, double cutoff)
+{
+    const int n = t->n, ld = t->ld;
+    const int m = t->m;
+    memset(t->skip, 0, (size_t)t->mcap);
+    int stall = 0;
+    double last_obj = -INFINITY;
+    const double *d = t->D + (size_t)t->mcap * ld;
+    for (;;) {
+        if (t->pivots >= t->max_pivots) return LP_ITERLIMIT;
+        const double cur = objective(t);
+        if (cur > last_obj + 1e-12 * fmax(1.0, fabs(cur))) { stall = 0; last_obj = cur; } else stall++;
+        const int bland = stall > 30;
+        int r = -1; double worst = ORC_PTOL; int rb = -1; int rb_id = 0x7fffffff;
+        for (int i = 0; i < m; ++i) {
+            if (t->skip[i]) continue;
+            const int j = t->basic[i];
+            const double v = fmax(t->lo[j] - t->xB[i], t->xB[i] - t->hi[j]);
+            if (v > worst) { worst = v; r = i; }
+            if (v > ORC_PTOL && j < rb_id) { rb_id = j; rb = i; }
+        }
+        if (r < 0) {
+            if (check_residual(t) > ORC_RESID_TOL) { refactor(t); memset(t->skip, 0, (size_t)t->mcap); continue; }
+            return LP_OPTIMAL;
+        }
+        if (bland) r = rb;
+        if (cur >= cutoff) return LP_CUTOFF;
+        const int jr = t->basic[r];
+        const double vlo = t->lo[jr] - t->xB[r], vhi = t->xB[r] - t->hi[jr];
+        const int below = vlo > vhi;
+        const double viol = below ? vlo : vhi;
+        const double *row = t->D + (size_t)r * ld;
+        /* eligible columns and the row's largest eligible magnitude */
+        double emax = 0;
+        for (int c = 0; c < n; ++c) {
+            const int j = t->nonbasic[c];
+            if (t->lo[j] == t->hi[j]) continue;
+            const double a = row[c];
+            const int el = below ? (t->at_upper[c] ? a > 0 : a < 0) : (t->at_upper[c] ? a < 0 : a > 0);
+            if (el && fabs(a) > emax) emax = fabs(a);
+        }
+        const double ptol = fmax(ORC_PIV_ABS, ORC_PIV_REL * emax);
+        double tmax = INFINITY, rmin = INFINITY;
+        int any = 0;
+        for (int c = 0; c < n; ++c) {
+            const int j = t->nonbasic[c];
+            if (t->lo[j] == t->hi[j]) continue;
+            const double a = row[c];
+            const int el = below ? (t->at_upper[c] ? a > 0 : a < 0) : (t->at_upper[c] ? a < 0 : a > 0);
+            if (!el || fabs(a) <= ptol) continue;
+            any = 1;
+            const double da = fmax(t->at_upper[c] ? -d[c] : d[c], 0.0);
+            const double r1 = (da + ORC_DTOL) / fabs(a), r0 = da / fabs(a);
+            if (r1 < tmax) tmax = r1;
+            if (r0 < rmin) rmin = r0;
+        }
+        if (!any) {
+            if (viol <= ORC_PTOL_SKIP) { t->skip[r] = 1; continue; }
+            return LP_INFEASIBLE;
+        }
+        int cbest = -1; double abest = -1; int idbest = 0x7fffffff;
+        for (int c = 0; c < n; ++c) {
+            const int j = t->nonbasic[c];
+            if (t->lo[j] == t->hi[j]) continue;
+            const double a = row[c];
+            const int el = below ? (t->at_upper[c] ? a > 0 : a < 0) : (t->at_upper[c] ? a < 0 : a > 0);
+            if (!el || fabs(a) <= ptol) continue;
+            const double da = fmax(t->at_upper[c] ? -d[c] : d[c], 0.0);
+            const double r0 = da / fabs(a);
+            if (bland) {
+                if (r0 <= rmin * (1 + 1e-12) + 1e-300 && j < idbest) { idbest = j; cbest = c; }
+            } else if (r0 <= tmax && fabs(a) > abest) { abest = fabs(a); cbest = c; }
+        }
+        pivot(t, r, cbest, below ? t->lo[jr] : t->hi[jr]);
+    }
+}
+
+/* row-activity bound propagation with integer rounding (Savelsbergh 1994); returns 0 if infeasible */
+static int propagate_bounds(const double *G, const double *h, int m, int n, double *lb, double *ub,
+                            const unsigned char *is_int)
+{
+    for (int pass = 0; pass < 4; ++pass) {
+        int changed = 0;
+        for (int i = 0; i < m; ++i) {
+            const double *g = G + (size_t)i * n;
+            double tot = 0; int ninf = 0, jinf = -1, nnz = 0;
+            for (int j = 0; j < n; ++j) {
+                if (g[j] == 0) continue;
+                nnz++;
+                const double lc = g[j] > 0 ? g[j] * lb[j] : g[j] * ub[j];
+                if (isinf(lc)) { ninf++; jinf = j; } else tot += lc;
+            }
+            if (!nnz) { if (h[i] < -1e-9) return 0; continue; }
+            if (!ninf && tot > h[i] + 1e-7 * fmax(1.0, fabs(h[i]))) return 0;
+            if (ninf > 1) continue;
+            for (int j = 0; j < n; ++j) {
+                if (g[j] == 0) continue;
+                double rest;
+                if (!ninf) rest = tot - (g[j] > 0 ? g[j] * lb[j] : g[j] * ub[j]);
+                else if (j == jinf) rest = tot;
+                else continue;
+                double b = (h[i] - rest) / g[j];
+                if (g[j] > 0) {
+                    if (is_int[j]) b = floor(b + 1e-7);
+                    if (b < ub[j] - 1e-9 * fmax(1.0, fabs(b))) { ub[j] = b; changed = 1; }
+                } else {
+                    if (is_int[j]) b = ceil(b - 1e-7);
+                    if (b > lb[j] + 1e-9 * fmax(1.0, fabs(b))) { lb[j] = b; changed = 1; }
+                }
+            }
+        }
+        for (int j = 0; j < n; ++j) { if (lb[j] > ub[j] + 1e-7) return 0; if (ub[j] < lb[j]) ub[j] = lb[j]; }
+        if (!changed) break;
+    }
+    return 1;
+}
+
+typedef struct { double key; int r; } frac_t;
+static int frac_cmp(const void *a, const void *b)
+{
+    const frac_t *x = (const frac_t *)a, *y = (const frac_t *)b;
+    if (x->key < y->key) return -1;
+    if (x->key > y->key) return 1;
+    return x->r - y->r;
+}
+
+static int gmi_round(dict_t *t, int max_cuts)
+{
+    const int n = t->n, ld = t->ld, m = t->m;
+    frac_t *fr = (frac_t *)calloc(m + 1, sizeof(frac_t));
+    int nf = 0;
+    for (int r = 0; r < m; ++r) {
+        const int j = t->basic[r];
+        if (j < n && t->is_int[j]) {
+            const double f0 = t->xB[r] - floor(t->xB[r]);
+            if (f0 > 1e-3 && f0 < 1 - 1e-3) { fr[nf].key = fabs(f0 - 0.5); fr[nf].r = r; nf++; }
+        }
+    }
+    qsort(fr, nf, sizeof(frac_t), frac_cmp);
+    double *x = dalloc(n), *g = dalloc(n), *ax = dalloc(n);
+    for (int c = 0; c < n; ++c) if (t->nonbasic[c] < n) x[t->nonbasic[c]] = t->xN[c];
+    for (int r = 0; r < m; ++r) if (t->basic[r] < n) x[t->basic[r]] = t->xB[r];
+    int added = 0;
+    const int m_start = m;
+    for (int f = 0; f < nf; ++f) {
+        if (m_start + added >= t->mcap || added >= max_cuts) break;
+        const int r = fr[f].r;
+        const double f0 = t->xB[r] - floor(t->xB[r]);
+        const double *row = t->D + (size_t)r * ld;
+        double gmin = INFINITY, gmax = 0;
+        for (int c = 0; c < n; ++c) {
+            const int j = t->nonbasic[c];
+            double a = (t->lo[j] == t->hi[j]) ? 0.0 : (t->at_upper[c] ? -row[c] : row[c]);
+            if (fabs(a) < ORC_COEF_ZERO) a = 0.0;
+            double gc;
+            if (j < n && t->is_int[j]) {
+                double fj = a - floor(a);
+                if (fj < ORC_COEF_ZERO || fj > 1 - ORC_COEF_ZERO) fj = 0.0;
+                gc = fj <= f0 ? fj / f0 : (1 - fj) / (1 - f0);
+            } else gc = a > 0 ? a / f0 : -a / (1 - f0);
+            g[c] = gc;
+            if (gc > 0) { if (gc < gmin) gmin = gc; if (gc > gmax) gmax = gc; }
+        }
+        if (gmax <= 0 || gmax / gmin > 1e6) continue;
+        /* sum_c g_c t_c >= 1  over structural variables:  ax.x <= bx */
+        for (int j = 0; j < n; ++j) ax[j] = 0;
+        double bx = -1.0;
+        for (int c = 0; c < n; ++c) {
+            if (g[c] <= 0) continue;
+            const int j = t->nonbasic[c];
+            const double sg = t->at_upper[c] ? -1.0 : 1.0;
+            if (j < n) { const double bnd = t->at_upper[c] ? t->hi[j] : t->lo[j]; ax[j] -= g[c] * sg; bx -= g[c] * sg * bnd; }
+            else { const int i = j - n; const double *gi = t->Gx + (size_t)i * n; for (int k = 0; k < n; ++k) ax[k] += g[c] * gi[k]; bx += g[c] * t->hx[i]; }
+        }
+        double nrm = 0;
+        for (int j = 0; j < n; ++j) if (fabs(ax[j]) > nrm) nrm = fabs(ax[j]);
+        if (nrm <= 0) continue;
+        const int k = m_start + added;
+        double *gk = t->Gx + (size_t)k * n, *dk = t->D + (size_t)k * ld;
+        double s_now = bx / nrm, dx = 0;
+        for (int j = 0; j < n; ++j) { gk[j] = ax[j] / nrm; s_now -= gk[j] * x[j]; }
+        t->hx[k] = bx / nrm;
+        for (int c = 0; c < n; ++c) { const double sg = t->at_upper[c] ? -1.0 : 1.0; dk[c] = -(g[c] / nrm) * sg; dx += dk[c] * t->xN[c]; }
+        dk[n] = s_now + dx;
+        t->basic[k] = n + k; t->where[n + k] = -1 - k;
+        added++;
+    }
+    t->m = m_start + added;
+    if (added) refresh(t);
+    free(fr); free(x); free(g); free(ax);
+    return added;
+}
+
+static double gtol(const orc_opts *o, double v) { return fmax(o->gap_abs, o->gap_rel * fabs(v)); }
+
+int orc_solve_milp(int n, int m, const double *q, const double *G, const double *h, const double *lb_in,
+                   const double *ub_in, const unsigned char *is_bin, const orc_opts *o, double *x_out,
+                   double *obj_out, orc_stats *st)
+{
+    memset(st, 0, sizeof(*st));
+    st->root_lp = st->root_bound = NAN; st->lower_bound = -INFINITY;
+    *obj_out = INFINITY;
+    double *lb = dalloc(n), *ub = dalloc(n);
+    memcpy(lb, lb_in, sizeof(double) * n); memcpy(ub, ub_in, sizeof(double) * n);
+    int status = ORC_INFEASIBLE;
+    if (o->presolve && !propagate_bounds(G, h, m, n, lb, ub, is_bin)) { st->status = status; free(lb); free(ub); return status; }
+    dict_t T; dict_t *t = &T; memset(t, 0, sizeof(T));
+    t->n = n; t->m0 = m; t->m = m; t->mcap = m + o->max_cuts; t->ld = n + 1; t->ntot = n + t->mcap;
+    t->max_pivots = o->max_pivots > 0 ? o->max_pivots : 2000000000L;
+    t->D = dalloc((size_t)(t->mcap + 1) * t->ld);
+    t->Gx = dalloc((size_t)t->mcap * n); t->hx = dalloc(t->mcap);
+    t->q = dalloc(n); t->rs = dalloc(m); t->cs = dalloc(n);
+    t->lo = dalloc(t->ntot); t->hi = dalloc(t->ntot);
+    t->xB = dalloc(t->mcap); t->xN = dalloc(n);
+    t->basic = (int *)calloc(t->mcap + 1, sizeof(int)); t->nonbasic = (int *)calloc(n + 1, sizeof(int));
+    t->where = (int *)calloc(t->ntot + 1, sizeof(int));
+    t->at_upper = (unsigned char *)calloc(n + 1, 1); t->is_int = (unsigned char *)calloc(n + 1, 1);
+    t->skip = (unsigned char *)calloc(t->mcap + 1, 1);
+    t->tmp_col = dalloc(t->mcap + 1); t->tmp_row = dalloc(n + 1);
+    memcpy(t->is_int, is_bin, n);
+    equilibrate(G, m, n, t->is_int, t->rs, t->cs);
+    for (int i = 0; i < m; ++i) {
+        for (int j = 0; j < n; ++j) t->Gx[(size_t)i * n + j] = G[(size_t)i * n + j] * t->rs[i] * t->cs[j];
+        t->hx[i] = h[i] * t->rs[i];
+    }
+    for (int j = 0; j < n; ++j) { t->q[j] = q[j] * t->cs[j]; t->lo[j] = lb[j] / t->cs[j]; t->hi[j] = ub[j] / t->cs[j]; }
+    for (int i = 0; i < t->mcap; ++i) { t->lo[n + i] = 0; t->hi[n + i] = INFINITY; }
+    reset_dictionary(t);
+    for (int c = 0; c < n; ++c) place(t, c);
+    refresh(t);
+
+    int *bins = (int *)calloc(n + 1, sizeof(int)); int nb = 0;
+    for (int j = 0; j < n; ++j) if (is_bin[j]) bins[nb++] = j;
+    double *root_lo = dalloc(n), *root_hi = dalloc(n), *xs = dalloc(n), *xo = dalloc(n);
+    double best = INFINITY; int have = 0;
+    int *stk_j = (int *)calloc(nb + 2, sizeof(int));
+    (void)0;
+    double *stk_first = dalloc(nb + 2);
+    unsigned char *stk_second = (unsigned char *)calloc(nb + 2, 1);
+    int *sv_j = (int *)calloc(nb + 2, sizeof(int)); double *sv_lo = dalloc(nb + 2), *sv_hi = dalloc(nb + 2);
+    int lp = dual_simplex(t, INFINITY);
+    st->nodes = 1;
+    if (lp != LP_OPTIMAL) { status = lp == LP_INFEASIBLE ? ORC_INFEASIBLE : ORC_NUMERICAL; goto done; }
+    st->root_lp = objective(t);
+    int stalled = 0;
+    for (int rnd = 0; rnd < o->cut_rounds; ++rnd) {
+        const double before = objective(t);
+        const int k = gmi_round(t, o->cuts_per_round);
+        if (!k) break;
+        st->cuts += k;
+        lp = dual_simplex(t, INFINITY);
+        if (lp != LP_OPTIMAL) { status = lp == LP_INFEASIBLE ? ORC_INFEASIBLE : ORC_NUMERICAL; goto done; }
+        if (objective(t) - before < 1e-6 * fmax(1.0, fabs(before))) { if (++stalled >= 2) break; } else stalled = 0;
+    }
+    st->root_bound = objective(t);
+    memcpy(root_lo, t->lo, sizeof(double) * n); memcpy(root_hi, t->hi, sizeof(double) * n);
+    {
+        /* Depth-first branch-and-bound with iterative deepening on the LP bound (Korf 1985): pass k
+         * explores every node whose bound is <= min(T_k, incumbent - tol).  T starts at the root bound
+         * (finds an optimal vertex of the optimal face quickly when the root bound is tight), grows
+         * geometrically while no incumbent exists and becomes +inf once one does. */
+        const double root_bound = st->root_bound;
+        int nodes = 0, limit = 0, pass = 0;
+        double T = root_bound + fmax(1e-7 * fmax(1.0, fabs(root_bound)), gtol(o, root_bound));
+        status = ORC_NODE_LIMIT;
+        for (;;) {
+            int depth = 0;
+            double t_next = INFINITY;   /* smallest bound among nodes pruned by T only */
+            int finished = 0;
+            pass++;
+            for (;;) {
+                /* ---- evaluate the current node */
+                nodes++;
+                int branch_j = -1; double branch_x = 0;
+                const double inc_cut = have ? best - gtol(o, best) : INFINITY;
+                const double cut = fmin(T, inc_cut);
+                lp = dual_simplex(t, cut + 1e-12);
+                if (lp == LP_ITERLIMIT) limit = 1;
+                else if (lp == LP_OPTIMAL || lp == LP_CUTOFF) {
+                    const double obj = objective(t);
+                    if (lp == LP_CUTOFF || obj > cut) { if (obj <= inc_cut && obj < t_next) t_next = obj; }
+                    else {
+                        for (int c = 0; c < n; ++c) if (t->nonbasic[c] < n) xs[t->nonbasic[c]] = t->xN[c];
+                        for (int r = 0; r < t->m; ++r) if (t->basic[r] < n) xs[t->basic[r]] = t->xB[r];
+                        for (int k = 0; k < nb; ++k) {
+                            const int j = bins[k];
+                            if (fabs(xs[j] - rint(xs[j])) > ORC_INTTOL) { branch_j = j; branch_x = xs[j]; break; }
+                        }
+                        if (branch_j < 0) {
+                            /* leaf: fix every binary at its rounded value, re-solve, verify, restore */
+                            int ns = 0;
+                            for (int k = 0; k < nb; ++k) {
+                                const int j = bins[k];
+                                if (t->lo[j] != t->hi[j]) { sv_j[ns] = j; sv_lo[ns] = t->lo[j]; sv_hi[ns] = t->hi[j]; ns++; const double v = rint(xs[j]); set_bounds(t, j, v, v); }
+                            }
+                            if (dual_simplex(t, INFINITY) == LP_OPTIMAL) {
+                                for (int c = 0; c < n; ++c) if (t->nonbasic[c] < n) xo[t->nonbasic[c]] = t->xN[c] * t->cs[t->nonbasic[c]];
+                                for (int r = 0; r < t->m; ++r) if (t->basic[r] < n) xo[t->basic[r]] = t->xB[r] * t->cs[t->basic[r]];
+                                for (int k = 0; k < nb; ++k) xo[bins[k]] = rint(xo[bins[k]]);
+                                double ob = 0; for (int j = 0; j < n; ++j) ob += q[j] * xo[j];
+                                int feas = 1;
+                                for (int i = 0; i < m && feas; ++i) {
+                                    double sa = -h[i]; const double *gi = G + (size_t)i * n;
+                                    for (int j = 0; j < n; ++j) sa += gi[j] * xo[j];
+                                    if (sa * t->rs[i] > 1e-6) feas = 0;
+                                }
+                                if (feas && ob < best) { best = ob; have = 1; memcpy(x_out, xo, sizeof(double) * n); }
+                            }
+                            for (int k = 0; k < ns; ++k) set_bounds(t, sv_j[k], sv_lo[k], sv_hi[k]);
+                        }
+                    }
+                }
+                if (have && best <= root_bound + gtol(o, best)) { finished = 1; }
+                if (nodes >= o->max_nodes) limit = 1;
+                if (branch_j >= 0 && !limit && !finished) {
+                    const double first = branch_x >= 0.5 ? 1.0 : 0.0;
+                    stk_j[depth] = branch_j; stk_first[depth] = first; stk_second[depth] = 0; depth++;
+                    set_bounds(t, branch_j, first, first);
+                    continue; /* evaluate the child */
+                }
+                /* ---- backtrack */
+                if (limit || finished) { while (depth > 0) { depth--; set_bounds(t, stk_j[depth], root_lo[stk_j[depth]], root_hi[stk_j[depth]]); } break; }
+                while (depth > 0 && stk_second[depth - 1]) { depth--; set_bounds(t, stk_j[depth], root_lo[stk_j[depth]], root_hi[stk_j[depth]]); }
+                if (depth == 0) break;
+                stk_second[depth - 1] = 1;
+                { const int j = stk_j[depth - 1]; const double v = 1.0 - stk_first[depth - 1]; set_bounds(t, j, v, v); }
+            }
+            if (finished) { status = ORC_OPTIMAL; break; }
+            if (limit) break;
+            /* the pass was exhaustive for its threshold */
+            if (have && best - gtol(o, best) <= T) { status = ORC_OPTIMAL; break; }
+            if (!isfinite(t_next)) { status = have ? ORC_OPTIMAL : ORC_INFEASIBLE; break; }
+            if (have) T = INFINITY;
+            else T = fmax(t_next + 1e-9 * fmax(1.0, fabs(t_next)), T + ldexp(2.5e-4, 2 * pass) * fmax(1.0, fabs(T)));
+        }
+        st->nodes = nodes;
+        st->lower_bound = status == ORC_OPTIMAL ? best : root_bound;
+    }
+done:
+    st->pivots = (int)t->pivots; st->refactors = t->refactors; st->status = status;
+    *obj_out = have ? best : INFINITY;
+    free(lb); free(ub); free(t->D); free(t->Gx); free(t->hx); free(t->q); free(t->rs); free(t->cs); free(t->lo);
+    free(t->hi); free(t->xB); free(t->xN); free(t->basic); free(t->nonbasic); free(t->where); free(t->at_upper);
+    free(t->is_int); free(t->skip); free(t->tmp_col); free(t->tmp_row); free(bins); free(root_lo); free(root_hi);
+    free(xs); free(xo); free(stk_j); free(stk_first); free(stk_second); free(sv_j); free(sv_lo); free(sv_hi);
+    return status;
+}
+
+/* exhaustive enumeration over the binaries + LP per leaf, for known-answer tests on tiny problems */
+int orc_enumerate_milp(int n, int m, const double *q, const double *G, const double *h, const double *lb,
+                       const double *ub, const unsigned char *is_bin, double *x_out, double *obj_out)
+{
+    int bins[24], nb = 0;
+    for (int j = 0; j < n; ++j) if (is_bin[j]) { if (nb >= 24) return -1; bins[nb++] = j; }
+    double *l = dalloc(n), *u = dalloc(n), *x = dalloc(n);
+    unsigned char *nob = (unsigned char *)calloc(n + 1, 1);
+    orc_opts o = {1e-9, 0.0, 1, 0, 0, 0, 0, 0};
+    orc_stats st;
+    double best = INFINITY;
+    for (long mask = 0; mask < (1L << nb); ++mask) {
+        memcpy(l, lb, sizeof(double) * n); memcpy(u, ub, sizeof(double) * n);
+        for (int k = 0; k < nb; ++k) { const double v = (mask >> k) & 1; l[bins[k]] = u[bins[k]] = v; }
+        double ob;
+        const int s = orc_solve_milp(n, m, q, G, h, l, u, nob, &o, x, &ob, &st);
+        if (s == ORC_OPTIMAL && ob < best) { best = ob; memcpy(x_out, x, sizeof(double) * n); }
+    }
+    *obj_out = best;
+    free(l); free(u); free(x); free(nob);
+    return isfinite(best) ? ORC_OPTIMAL : ORC_INFEASIBLE;
+}
