@@ -1,0 +1,170 @@
+/*
+ * libmldgpu -- MI355X-native (gfx950) batched MLD-MPC solve path.  Plain C ABI: caller-owned,
+ * C-contiguous row-major `double` arrays; the library copies in/out and never keeps a host pointer
+ * past the call.  Every function returns 0 on success and a negative mld_err on failure; the text of
+ * the last error on the calling thread is mld_last_error().  A handle is not thread-safe; distinct
+ * handles are.  There is no CPU fallback: without a HIP device every compute entry point fails
+ * with MLD_ERR_NO_DEVICE.
+ *
+ * The reference (michchr/pyhybridcontrol) has no FFI: its seam for this path is the Python call
+ * `ConstraintSolvedController.solve()` -> `cvx.Problem.solve()` (controllers/controller_base.py:491-540,
+ * :509).  Each entry point below names the reference code it replaces; INTEGRATION.md shows the
+ * ctypes binding a maintainer would add on the reference side.
+ */
+#ifndef MLDGPU_H
+#define MLDGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mld_model mld_model_t;
+typedef struct mld_problem mld_problem_t;
+
+typedef enum {
+    MLD_OK = 0,
+    MLD_ERR_INVALID = -1,     /* bad argument / shape */
+    MLD_ERR_NO_DEVICE = -2,   /* no HIP device: the product path has no CPU fallback */
+    MLD_ERR_UNSUPPORTED = -3, /* e.g. quadratic cost passed to the MILP solver */
+    MLD_ERR_HIP = -4,         /* HIP runtime error (text in mld_last_error) */
+    MLD_ERR_COMM = -5         /* RCCL error */
+} mld_err;
+
+/* per-instance solve status (status_out of mld_solve_batch) */
+typedef enum {
+    MLD_STATUS_OPTIMAL = 0,
+    MLD_STATUS_INFEASIBLE = 1,
+    MLD_STATUS_NODE_LIMIT = 2, /* incumbent (if any) returned, gap = obj - lower_bound */
+    MLD_STATUS_NUMERICAL = 3
+} mld_status;
+
+/* MLD dimensions, models/mld_model.py:149-168 (MldInfo._mld_dim_map): nv = nu+ndelta+nz+nmu;
+ * binaries are the trailing nu_l / nmu_l entries of u / mu, all of delta, none of z (:294-345). */
+typedef struct {
+    int32_t nx, nu, ndelta, nz, nmu, nomega, ny, nc, nu_l, nmu_l;
+} mld_dims;
+
+/* flags */
+#define MLD_CONDENSE_DEFAULT 0
+
+/* Solver options.  max_nodes / gap_rel / time-like limits mirror the Gurobi parameters the reference
+ * forwards through **solver_kwargs (NodeLimit, MIPGap; micro_grid_control_simulation.py:232). */
+typedef struct {
+    double gap_abs;        /* absolute optimality tolerance (default 1e-9) */
+    double gap_rel;        /* relative MIP gap (Gurobi MIPGap; default 0 = prove optimality) */
+    int32_t max_nodes;     /* per instance (default 100000) */
+    int32_t max_pivots;    /* per instance simplex iteration limit (default 2000000) */
+    int32_t cut_rounds;    /* Gomory mixed-integer cut rounds at the root (default 8) */
+    int32_t cuts_per_round;/* default 40 */
+    int32_t max_cuts;      /* rows reserved for cuts (default 200) */
+    int32_t presolve;      /* bit0: per-instance bound propagation, bit1: per-model big-M tightening (default 3) */
+    int32_t n_slots;       /* resident workgroups (0 = auto: 2 per CU) */
+    int32_t reserved;
+} mld_opts;
+
+/* Linear cost in tiled horizon form (the Python layer parses the reference's string-keyed atoms,
+ * controllers/components/objective_atoms.py:453-521, and tiles per-step weights :118-137).
+ * Each pointer is n_models x len (or NULL = zeros):
+ *   lin_v  : N_tilde*nv   weight on v_tilde  (q_u, q_delta, q_z, q_mu, q_v atoms scattered into v order)
+ *   lin_x  : N_tilde*nx   weight on x_tilde  (pulled back through Gamma_v: variables.py:259-265)
+ *   lin_y  : N_tilde*ny   weight on y_tilde  (pulled back through L_v:     variables.py:269-275)
+ * Quadratic weights (symmetric, full horizon size, NULL = none): quad_v (n x n), quad_x, quad_y --
+ * cost  var' W var  (objective_atoms.py:321-331); they are assembled into P by mld_cost_assemble;
+ * mld_solve_batch itself accepts linear cost only in this version. */
+typedef struct {
+    const double *lin_v, *lin_x, *lin_y;
+    const double *quad_v, *quad_x, *quad_y;
+} mld_cost;
+
+typedef struct {
+    int64_t nodes, pivots, cuts, refactors; /* totals over the batch */
+    int32_t n_optimal, n_infeasible, n_node_limit, n_numerical;
+    double solve_ms;                         /* device time of the solve kernel(s), HIP events */
+    double rhs_ms;
+} mld_stats;
+
+/* ---- discovery / errors ------------------------------------------------------------------ */
+int mld_device_count(void);
+int mld_set_device(int device);
+const char *mld_last_error(void);
+const char *mld_version(void);
+int mld_device_info(char *name, int name_len, int *n_cu, int64_t *hbm_bytes, int *lds_bytes);
+
+/* ---- model --------------------------------------------------------------------------------
+ * n_models same-shaped MLD systems  x+ = A x + B1 u + B2 d + B3 z + B4 w + b5 ; y = C x + D1 u + ... ;
+ * E x + F1 u + F2 d + F3 z + F4 w + G y + Psi mu <= f5  (models/mld_model.py:456-463).
+ * `mats` holds 20 pointers in the order A,B1,B2,B3,B4,b5,C,D1,D2,D3,D4,d5,E,F1,F2,F3,F4,f5,G,Psi, each
+ * n_models x rows x cols row-major, NULL = zeros (the reference pads missing matrices with zeros,
+ * mld_model.py:910-928; C must be passed explicitly -- the Python layer applies the C=I default :515-520). */
+int mld_model_create(mld_model_t **out, const mld_dims *dims, int n_models, const double *const *mats);
+int mld_model_destroy(mld_model_t *);
+
+/* ---- condensing (kernels K1+K2) -----------------------------------------------------------
+ * Replaces MldEvoMatrices.gen_mld_evo_matrices (controllers/components/mld_evolution_matrices.py:107-244)
+ * and block_toeplitz / block_diag_dense (utils/matrix_utils.py:55-81,117-161).  Outputs (any may be
+ * NULL) are n_models x the exact materialised layout of the reference's *_N_tilde matrices:
+ *   Phi_x (N nx, nx)  Gamma_v (N nx, N nv)  Gamma_w (N nx, N nw)  Gamma_5 (N nx, 1)
+ *   L_x   (N ny, nx)  L_v     (N ny, N nv)  L_w     (N ny, N nw)  L_5     (N ny, 1)
+ *   H_x   (N nc, nx)  H_v     (N nc, N nv)  H_w     (N nc, N nw)  H_5     (N nc, 1)
+ * mld_condense_device computes into device-resident buffers owned by the model (no host traffic)
+ * and returns the device time of the condensing kernels; mld_condense = that + copies to host. */
+int mld_condense_device(mld_model_t *, int N_tilde, int flags, double *kernel_ms);
+int mld_condense(mld_model_t *, int N_tilde, int flags, double *Phi_x, double *Gamma_v, double *Gamma_w,
+                 double *Gamma_5, double *L_x, double *L_v, double *L_w, double *L_5, double *H_x, double *H_v,
+                 double *H_w, double *H_5);
+
+/* ---- problem ------------------------------------------------------------------------------
+ * Replaces MpcController.build (controllers/mpc_controller.py:76-101): condensed constraint maps
+ * (on device, from the big-M-tightened model), cost pull-back (kernel K4), scaling, bounds
+ * (mu >= 0, binaries in {0,1}: controllers/components/variables.py:189-243). */
+int mld_opts_default(mld_opts *);
+int mld_problem_create(mld_problem_t **out, mld_model_t *model, int N_p, int N_tilde, const mld_cost *cost,
+                       const mld_opts *opts);
+int mld_problem_set_cost(mld_problem_t *, const mld_cost *cost); /* prices change every MPC step */
+int mld_problem_destroy(mld_problem_t *);
+
+/* Cost assembly (kernel K4) read-back, n_models x ...: P (n,n) q0 (n) Qx (n,nx) Qw (n,N nw); any NULL.
+ * objective = 1/2 v'Pv + (q0 + Qx x_k + Qw w)'v + r(x_k,w)   (objective_atoms.py:308-331,523-532) */
+int mld_cost_assemble(mld_problem_t *, double *P, double *q0, double *Qx, double *Qw);
+
+/* ---- solve (kernels K3, K5, K6) -------------------------------------------------------------
+ * Replaces the backend call `self._problem.solve(...)` (controllers/controller_base.py:509) for
+ * `batch` independent instances:  model_idx[b] in [0,n_models) (NULL = all 0), x0 (batch, nx),
+ * omega (batch, N_tilde*nomega) step-major, fixed_bin (batch, n_bin) with 0/1 = fixed, 255 = free
+ * (NULL = all free; all fixed = relaxation-only mode).  Outputs: v_out (batch, N_tilde*nv) in the
+ * reference's v_tilde order [u0;d0;z0;mu0;u1;...] (variables.py:226-241), obj_out (batch) including
+ * the constant term, status_out (batch), lower_bound_out (batch, may be NULL), stats (may be NULL). */
+int mld_solve_batch(mld_problem_t *, int batch, const int32_t *model_idx, const double *x0, const double *omega,
+                    const uint8_t *fixed_bin, double *v_out, double *obj_out, int32_t *status_out,
+                    double *lower_bound_out, mld_stats *stats_out);
+
+/* The same in three steps so that a benchmark can time the device work with inputs resident in HBM. */
+int mld_upload_batch(mld_problem_t *, int batch, const int32_t *model_idx, const double *x0, const double *omega,
+                     const uint8_t *fixed_bin);
+int mld_solve_resident(mld_problem_t *, mld_stats *stats_out);
+int mld_download_results(mld_problem_t *, double *v_out, double *obj_out, int32_t *status_out,
+                         double *lower_bound_out, int32_t *nodes_out, int32_t *pivots_out);
+
+/* Constraint right-hand side only (kernel K3): h = H_x x_k + H_w w + H_5 per instance
+ * (controllers/controller_base.py:446-450); `scenarios`>1 applies the row-min over scenario columns
+ * of H_w Omega (:442-444) with omega laid out (batch, scenarios, N_tilde*nomega).  h_out (batch, N nc).
+ * Uses the ORIGINAL (un-tightened) model so that it can populate gen_evo_constraints. */
+int mld_rhs_batch(mld_problem_t *, int batch, int scenarios, const int32_t *model_idx, const double *x0,
+                  const double *omega, double *h_out);
+
+/* ---- multi-GPU result gather (RCCL over xGMI) ---------------------------------------------
+ * One process per GPU.  Rank 0 calls mld_comm_unique_id, the bytes are broadcast by the launcher
+ * (any side channel), every rank calls mld_comm_init.  mld_gather all-gathers `count` doubles per
+ * rank from a HOST buffer (staged through device memory) into recv (n_ranks*count). */
+#define MLD_COMM_ID_BYTES 128
+int mld_comm_unique_id(uint8_t id[MLD_COMM_ID_BYTES]);
+int mld_comm_init(int n_ranks, int rank, const uint8_t id[MLD_COMM_ID_BYTES]);
+int mld_gather(const double *send, int count, double *recv);
+int mld_comm_destroy(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLDGPU_H */
