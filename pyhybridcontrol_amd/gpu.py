@@ -93,3 +93,132 @@ class GpuModel(object):
                 ptrs.append(None)
         check(_lib.load().mld_condense(self._h, int(N_tilde), 0, *ptrs))
         return out
+
+
+def make_opts(**kw):
+    o = _lib.Opts()
+    check(_lib.load().mld_opts_default(C.byref(o)))
+    alias = dict(MIPGap="gap_rel", NodeLimit="max_nodes", IterationLimit="max_pivots")
+    for k, v in kw.items():
+        k = alias.get(k, k)
+        if not hasattr(o, k):
+            raise TypeError("unknown solver option %r" % k)
+        setattr(o, k, type(getattr(o, k))(v))
+    return o
+
+
+class GpuProblem(object):
+    """mld_problem_t: condensed constraint maps of a GpuModel + cost + solver workspace, on device."""
+
+    def __init__(self, model, N_p, N_tilde, cost=None, **opts):
+        self.model = model
+        self.N_p, self.N_tilde = int(N_p), int(N_tilde)
+        d = model.dims
+        self.n = self.N_tilde * model.nv
+        self.m = self.N_tilde * d["nc"]
+        self.nW = self.N_tilde * d["nomega"]
+        step_bin = np.zeros(model.nv, dtype=bool)
+        step_bin[d["nu"] - d["nu_l"]:d["nu"]] = True
+        step_bin[d["nu"]:d["nu"] + d["ndelta"]] = True
+        omu = d["nu"] + d["ndelta"] + d["nz"]
+        step_bin[omu + d["nmu"] - d["nmu_l"]:omu + d["nmu"]] = True
+        self.is_bin = np.tile(step_bin, self.N_tilde)
+        self.n_bin = int(self.is_bin.sum())
+        self.opts = make_opts(**opts)
+        self._h = C.c_void_p()
+        c, keep = self._cost_struct(cost)
+        check(_lib.load().mld_problem_create(C.byref(self._h), model._h, self.N_p, self.N_tilde,
+                                             C.byref(c) if c is not None else None, C.byref(self.opts)))
+        self.batch = 0
+
+    def _cost_struct(self, cost):
+        if not cost:
+            return None, []
+        M, d, N = self.model.n_models, self.model.dims, self.N_tilde
+        lens = dict(lin_v=(self.n,), lin_x=(N * d["nx"],), lin_y=(N * d["ny"],), quad_v=(self.n, self.n),
+                    quad_x=(N * d["nx"], N * d["nx"]), quad_y=(N * d["ny"], N * d["ny"]))
+        c = _lib.Cost()
+        keep = []
+        for k, shp in lens.items():
+            a = cost.get(k)
+            if a is None or int(np.prod(shp)) == 0:
+                setattr(c, k, None)
+                continue
+            a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float64).reshape((-1,) + shp), (M,) + shp))
+            keep.append(a)
+            setattr(c, k, _lib.dptr(a))
+        self._keep_cost = keep
+        return c, keep
+
+    def set_cost(self, cost):
+        c, keep = self._cost_struct(cost)
+        check(_lib.load().mld_problem_set_cost(self._h, C.byref(c) if c is not None else None))
+
+    def cost_assemble(self):
+        M, n, nx, nW = self.model.n_models, self.n, self.model.dims["nx"], self.nW
+        P, q0 = np.zeros((M, n, n)), np.zeros((M, n))
+        Qx, Qw = np.zeros((M, n, nx)), np.zeros((M, n, nW))
+        check(_lib.load().mld_cost_assemble(self._h, _lib.dptr(P), _lib.dptr(q0), _lib.dptr(Qx) if nx else None,
+                                            _lib.dptr(Qw) if nW else None))
+        return dict(P=P, q0=q0, Qx=Qx, Qw=Qw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().mld_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- batch ---------------------------------------------------------------------------------
+    def upload(self, x0, omega, model_idx=None, fixed_bin=None):
+        d = self.model.dims
+        x0 = _lib.as_f64(x0).reshape(-1, d["nx"]) if d["nx"] else np.zeros((np.shape(omega)[0] if omega is not None else 1, 0))
+        batch = x0.shape[0] if d["nx"] else int(np.asarray(omega).reshape(-1, max(self.nW, 1)).shape[0])
+        omega = _lib.as_f64(omega).reshape(batch, self.nW) if self.nW else np.zeros((batch, 0))
+        mi = np.ascontiguousarray(model_idx, dtype=np.int32) if model_idx is not None else None
+        fb = np.ascontiguousarray(fixed_bin, dtype=np.uint8).reshape(batch, self.n_bin) if fixed_bin is not None else None
+        check(_lib.load().mld_upload_batch(
+            self._h, batch, mi.ctypes.data_as(C.POINTER(C.c_int32)) if mi is not None else None,
+            _lib.dptr(x0) if d["nx"] else None, _lib.dptr(omega) if self.nW else None,
+            fb.ctypes.data_as(C.POINTER(C.c_uint8)) if fb is not None else None))
+        self.batch = batch
+        return batch
+
+    def solve_resident(self):
+        st = _lib.Stats()
+        check(_lib.load().mld_solve_resident(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in _lib.Stats._fields_}
+
+    def download(self):
+        b = self.batch
+        v, obj, lbnd = np.zeros((b, self.n)), np.zeros(b), np.zeros(b)
+        status, nodes, pivots = np.zeros(b, np.int32), np.zeros(b, np.int32), np.zeros(b, np.int32)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        check(_lib.load().mld_download_results(self._h, _lib.dptr(v), _lib.dptr(obj), ip(status), _lib.dptr(lbnd),
+                                               ip(nodes), ip(pivots)))
+        return dict(v=v, obj=obj, status=status, lower_bound=lbnd, nodes=nodes, pivots=pivots)
+
+    def solve(self, x0, omega, model_idx=None, fixed_bin=None):
+        self.upload(x0, omega, model_idx, fixed_bin)
+        stats = self.solve_resident()
+        out = self.download()
+        out["stats"] = stats
+        return out
+
+    def rhs(self, x0, omega, model_idx=None, scenarios=1):
+        """h = H_x x_k + H_omega omega + H_5 (row-min over `scenarios` omega columns), original model"""
+        d = self.model.dims
+        omega = _lib.as_f64(omega)
+        batch = int(np.asarray(x0).reshape(-1, d["nx"]).shape[0]) if d["nx"] else int(omega.size // max(1, scenarios * self.nW))
+        x0 = _lib.as_f64(x0).reshape(batch, d["nx"]) if d["nx"] else np.zeros((batch, 0))
+        omega = omega.reshape(batch, scenarios, self.nW) if self.nW else np.zeros((batch, scenarios, 0))
+        mi = np.ascontiguousarray(model_idx, dtype=np.int32) if model_idx is not None else None
+        h = np.zeros((batch, self.m))
+        check(_lib.load().mld_rhs_batch(self._h, batch, int(scenarios),
+                                        mi.ctypes.data_as(C.POINTER(C.c_int32)) if mi is not None else None,
+                                        _lib.dptr(x0) if d["nx"] else None, _lib.dptr(omega) if self.nW else None, _lib.dptr(h)))
+        return h
