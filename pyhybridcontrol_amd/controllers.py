@@ -1,0 +1,396 @@
+"""Host-side mirror of the reference's MPC controller API, backed by libmldgpu (no cvxpy, no CPU solver).
+
+Mirrors, for the hot path only:
+  * ``MldEvoMatrices``            controllers/components/mld_evolution_matrices.py:19-250
+  * ``ConstraintSolvedController`` / ``MpcController``
+                                  controllers/controller_base.py:149-548, controllers/mpc_controller.py:19-101
+  * ``ControllerBuildRequiredError`` / ``ControllerSolverError``   controller_base.py:25-30
+with the same method names, argument meaning and error behaviour:
+``build()`` -> problem on the GPU; ``solve()`` -> objective value (float) or ControllerSolverError;
+``feedback()`` -> variables at step k; ``sim_step_k()`` -> plant step + log; ``external_solve``
+bypasses the backend (controller_base.py:507,536-538).  Where the reference builds cvxpy expressions,
+this keeps numeric arrays.  Unsupported reference features raise NotImplementedError loudly
+(extra constraint blocks, disable_soft_constraints, L1/Linf/rate atoms, time-varying horizons).
+"""
+import time
+
+import numpy as np
+
+from . import gpu
+from ._lib import MldGpuError, STATUS_NAMES
+from .mld_model import MldModel
+from .objective_atoms import ObjectiveAtoms, atleast_2d_col
+
+
+class ControllerBuildRequiredError(RuntimeError):
+    pass
+
+
+class ControllerSolverError(RuntimeError):
+    pass
+
+
+_EVO = dict(state_input=("Phi_x", "Gamma_v", "Gamma_omega", "Gamma_5"), output=("L_x", "L_v", "L_omega", "L_5"),
+            constraint=("H_x", "H_v", "H_omega", "H_5"))
+_ROWS = dict(state_input="nx", output="ny", constraint="nc")
+
+
+class MldEvoMatrices(dict):
+    """{'state_input'|'output'|'constraint': {name_N_tilde, name_N_p}} computed by kernels K1+K2.
+
+    x_N_tilde = Phi_x x(0) + Gamma_v v_N_tilde + Gamma_omega omega_N_tilde + Gamma_5
+    y_N_tilde = L_x x(0) + L_v v_N_tilde + L_omega omega_N_tilde + L_5
+    H_v v_N_tilde <= H_x x(0) + H_omega omega_N_tilde + H_5          (mld_evolution_matrices.py:59-67)
+    """
+
+    def __init__(self, controller=None, N_p=None, N_tilde=None, mld_numeric_k=None, mld_numeric_tilde=None):
+        super(MldEvoMatrices, self).__init__()
+        if mld_numeric_tilde:
+            raise NotImplementedError("time-varying horizons (mld_numeric_tilde) are SURVEY 8f item 3 (next)")
+        self._controller = controller
+        self.N_p = N_p if N_p is not None else controller.N_p
+        self.N_tilde = N_tilde if N_tilde is not None else (controller.N_tilde if controller else self.N_p + 1)
+        self._model = mld_numeric_k if mld_numeric_k is not None else controller.mld_numeric_k
+        if not isinstance(self._model, MldModel):
+            raise ValueError("mld_numeric_k must be an MldModel with mld_type=='numeric'")
+        self._gpu_model = None
+        self.update(reset=True)
+
+    @property
+    def mld_info_k(self):
+        return self._model.mld_info
+
+    @property
+    def state_input(self):
+        return self["state_input"]
+
+    @property
+    def output(self):
+        return self["output"]
+
+    @property
+    def constraint(self):
+        return self["constraint"]
+
+    def gpu_model(self):
+        if self._gpu_model is None:
+            self._gpu_model = gpu.GpuModel([self._model.as_mats()], self._model.mld_info.as_gpu_dims())
+        return self._gpu_model
+
+    def update(self, reset=False, **_):
+        if not reset and self:
+            return
+        dims = self._model.mld_info.as_gpu_dims()
+        evo = self.gpu_model().condense(self.N_tilde)
+        for typ, names in _EVO.items():
+            rows = dims[_ROWS[typ]]
+            blk = {}
+            for nm in names:
+                M = evo[nm][0]
+                blk[nm + "_N_tilde"] = M
+                blk[nm + "_N_p"] = M[:self.N_p * rows, :]           # row-prefix views (:246-250)
+            self[typ] = blk
+
+    def get_evo_matrices_N_tilde(self, N_tilde=None):
+        """row-prefix slices for a shorter constraint horizon (:89-105)"""
+        if N_tilde is None or N_tilde == self.N_tilde:
+            return self
+        if N_tilde > self.N_tilde:
+            raise ValueError("N_tilde:%d cannot be greater than self.N_tilde:%d" % (N_tilde, self.N_tilde))
+        out = dict.__new__(MldEvoMatrices)
+        dict.__init__(out)
+        out.__dict__.update(self.__dict__)
+        dims = self._model.mld_info.as_gpu_dims()
+        for typ in _EVO:
+            rows = dims[_ROWS[typ]]
+            out[typ] = {k: (v[:N_tilde * rows, :] if k.endswith("N_tilde") else v) for k, v in self[typ].items()}
+        return out
+
+
+class EvoConstraint(object):
+    """numeric stand-in for the cvxpy constraint  LHS @ v <= RHS  returned by gen_evo_constraints"""
+
+    def __init__(self, H_v, rhs):
+        self.H_v, self.rhs = H_v, rhs
+
+
+class MldSimLog(dict):
+    """k -> dict of column vectors (controller_base.py:58-146), without the DataFrame sugar"""
+
+    def set_sim_k(self, k, sim_k=None, **kwargs):
+        self.pop(k, None)
+        self.update_sim_k(k, sim_k, **kwargs)
+
+    def update_sim_k(self, k, sim_k=None, **kwargs):
+        entry = dict(self.get(k, {}))
+        for name, val in dict(sim_k or {}, **kwargs).items():
+            if val is not None:
+                entry[name] = atleast_2d_col(val)
+        self[k] = entry
+
+
+class MpcController(object):
+    def __init__(self, model=None, x_k=None, omega_tilde_k=None, N_p=None, N_tilde=None, agent=None, mld_numeric=None,
+                 **solver_opts):
+        if agent is not None:
+            raise NotImplementedError("agent ownership layer (models/agents.py) is out of scope; pass model=")
+        model = model if model is not None else mld_numeric
+        if not isinstance(model, MldModel):
+            model = MldModel(model)
+        self._model = model
+        self._N_p = N_p if N_p is not None else 0
+        self._N_tilde = N_tilde if N_tilde is not None else self._N_p + 1
+        self._solver_opts = dict(solver_opts)
+        self._sim_log = MldSimLog()
+        self._solve_time_overall = 0
+        self._solve_time_solver = 0
+        self.reset_components(x_k=x_k, omega_tilde_k=omega_tilde_k)
+
+    # -- state ----------------------------------------------------------------------------------
+    def reset_components(self, x_k=None, omega_tilde_k=None):
+        info = self.mld_info_k
+        self._build_required = True
+        self._mld_evo_matrices = None
+        self._std_obj_atoms = ObjectiveAtoms(info.as_gpu_dims(), self._N_p, self._N_tilde)
+        self._problem = None
+        self._sense = 1.0
+        self._solution = None
+        self._x_k = np.zeros((info.nx, 1))
+        self._omega_tilde_k = np.zeros((info.nomega * self._N_tilde, 1))
+        if x_k is not None:
+            self.x_k = x_k
+        if omega_tilde_k is not None:
+            self.omega_tilde_k = omega_tilde_k
+
+    @property
+    def N_p(self):
+        return self._N_p
+
+    @property
+    def N_tilde(self):
+        return self._N_tilde
+
+    @property
+    def mld_numeric_k(self):
+        return self._model
+
+    @property
+    def mld_info_k(self):
+        return self._model.mld_info
+
+    @property
+    def mld_evo_matrices(self):
+        if self._mld_evo_matrices is None:
+            self._mld_evo_matrices = MldEvoMatrices(self)
+        return self._mld_evo_matrices
+
+    @property
+    def std_obj_atoms(self):
+        return self._std_obj_atoms
+
+    @property
+    def sim_log(self):
+        return self._sim_log
+
+    @property
+    def build_required(self):
+        return self._build_required
+
+    def set_build_required(self):
+        self._build_required = True
+
+    @property
+    def x_k(self):
+        return self._x_k
+
+    @x_k.setter
+    def x_k(self, value):
+        self._x_k = self._check_shape("x_k", value, (self.mld_info_k.nx, 1))
+
+    @property
+    def omega_tilde_k(self):
+        return self._omega_tilde_k
+
+    @omega_tilde_k.setter
+    def omega_tilde_k(self, value):
+        self._omega_tilde_k = self._check_shape("omega_tilde_k", value, (self.mld_info_k.nomega * self._N_tilde, 1))
+
+    @staticmethod
+    def _check_shape(name, value, required):
+        value = atleast_2d_col(value)
+        if value.dtype == np.object_:
+            raise TypeError("'new_value' must be a numeric array like object or None.")
+        if 0 in required:
+            return np.empty(required)
+        if value.shape != required:
+            raise ValueError("Incorrect shape:%s for %s, a shape of %s is required." % (value.shape, name, required))
+        return value.astype(np.float64)
+
+    # -- objective / constraints -------------------------------------------------------------------
+    def set_std_obj_atoms(self, objective_atoms_struct=None, **kwargs):
+        self._std_obj_atoms.set(objective_atoms_struct, **kwargs)
+        self._build_required = True
+
+    def update_std_obj_atoms(self, objective_weights_struct=None, **kwargs):
+        self._std_obj_atoms.update(objective_weights_struct, **kwargs)
+        self._build_required = True
+
+    def gen_evo_constraints(self, x_k=None, omega_tilde_k=None, omega_scenarios_k=None, N_tilde=None):
+        """H_v v <= H_x x_k + H_omega omega + H_5 ; with omega_scenarios_k the row-min over scenario
+        columns of H_omega @ Omega (controller_base.py:411-456).  RHS computed by kernel K3."""
+        x_k = self._x_k if x_k is None else self._check_shape("x_k", x_k, (self.mld_info_k.nx, 1))
+        N_t = self._N_tilde if N_tilde is None else N_tilde
+        if not N_t <= self._N_tilde:
+            raise ValueError("N_tilde: %d must be less or equal to self.N_tilde: %d" % (N_t, self._N_tilde))
+        info = self.mld_info_k
+        if not info.n_constraints:
+            return EvoConstraint(np.zeros((0, self._N_tilde * info.nv)), np.zeros((0, 1)))
+        prob = self._ensure_problem()
+        if omega_scenarios_k is not None:
+            Om = np.asarray(omega_scenarios_k, dtype=np.float64)
+            if Om.shape[0] == N_t * info.nomega and N_t < self._N_tilde:
+                Om = np.vstack([Om, np.zeros(((self._N_tilde - N_t) * info.nomega, Om.shape[1]))])
+            h = prob.rhs(x_k.T, Om.T[np.newaxis], scenarios=Om.shape[1])[0]
+        else:
+            om = self._omega_tilde_k if omega_tilde_k is None else atleast_2d_col(omega_tilde_k)
+            if om.shape[0] == N_t * info.nomega and N_t < self._N_tilde:
+                om = np.vstack([om, np.zeros(((self._N_tilde - N_t) * info.nomega, 1))])
+            h = prob.rhs(x_k.T, om.T)[0]
+        rows = N_t * info.n_constraints
+        H_v = self.mld_evo_matrices.constraint["H_v_N_tilde"][:rows]
+        return EvoConstraint(H_v, h[:rows].reshape(-1, 1))
+
+    def set_constraints(self, std_evo_constaints=None, other_constraints=None, disable_soft_constraints=False):
+        if other_constraints:
+            raise NotImplementedError("extra constraint blocks (scenario / min-max variants) are SURVEY 8f item 2 (next)")
+        if disable_soft_constraints and self.mld_info_k.nmu:
+            raise NotImplementedError("disable_soft_constraints (mu == 0) is not on the GPU path yet")
+        self._build_required = True
+
+    def _ensure_problem(self):
+        if self._problem is None:
+            evo = self.mld_evo_matrices
+            cost = self._std_obj_atoms.to_cost()
+            self._omega_atoms = cost.pop("_omega_atoms", [])
+            self._problem = gpu.GpuProblem(evo.gpu_model(), self._N_p, self._N_tilde, self._signed(cost), **self._solver_opts)
+        return self._problem
+
+    def _signed(self, cost):
+        return {k: (None if v is None else self._sense * np.asarray(v)) for k, v in cost.items()}
+
+    def build(self, with_std_objective=True, with_std_constraints=True, sense=None, disable_soft_constraints=False):
+        """mpc_controller.py:76-101"""
+        if not with_std_constraints:
+            raise NotImplementedError("with_std_constraints=False")
+        self.set_constraints(disable_soft_constraints=disable_soft_constraints)
+        sense = "minimize" if sense is None else sense
+        if sense.lower().startswith("min"):
+            self._sense = 1.0
+        elif sense.lower().startswith("max"):
+            self._sense = -1.0
+        else:
+            raise ValueError("Problem 'sense' must be either 'minimize' or 'maximize', got '%s'." % sense)
+        cost = self._std_obj_atoms.to_cost() if with_std_objective else {}
+        self._omega_atoms = cost.pop("_omega_atoms", []) if cost else []
+        if self._problem is None:
+            self._ensure_problem()
+        self._problem.set_cost(self._signed(cost) if cost else None)
+        self._build_required = False
+
+    # -- solve -------------------------------------------------------------------------------------
+    def solve(self, k, x_k=None, omega_tilde_k=None, external_solve=None, solver=None, verbose=False, warm_start=True,
+              parallel=False, *args, method=None, **kwargs):
+        """controller_base.py:491-540.  `solver`, `warm_start`, `parallel`, `method` are accepted for
+        signature compatibility and ignored; Gurobi-style kwargs MIPGap / NodeLimit are honoured."""
+        start = time.time()
+        try:
+            if x_k is not None:
+                self.x_k = x_k
+            if omega_tilde_k is not None:
+                self.omega_tilde_k = omega_tilde_k
+            if self._build_required:
+                raise ControllerBuildRequiredError(
+                    "%s problem has not been built or needs to be rebuilt." % self.__class__.__name__)
+            if external_solve is not None:
+                self._solve_time_solver = 0
+                return external_solve
+            remap = {}
+            for key, val in kwargs.items():
+                if key in ("MIPGap", "NodeLimit", "IterationLimit"):
+                    remap[key] = val
+                elif key not in ("TimeLimit",):
+                    raise TypeError("unsupported solver option %r" % key)
+            if remap and remap != getattr(self, "_last_remap", None):
+                self._solver_opts.update(remap)
+                self._last_remap = remap
+                self._problem.close()
+                self._problem = None
+                self.build(sense="min" if self._sense > 0 else "max")
+            try:
+                out = self._problem.solve(self._x_k.T, self._omega_tilde_k.T)
+            except MldGpuError as e:
+                self._solve_time_solver = np.nan
+                raise ControllerSolverError(str(e)) from e
+            self._solve_time_solver = out["stats"]["solve_ms"] * 1e-3
+            status = STATUS_NAMES[int(out["status"][0])]
+            solution = self._sense * float(out["obj"][0])
+            if verbose:
+                print("mldgpu: status=%s objective=%r nodes=%d pivots=%d" % (status, solution, out["nodes"][0], out["pivots"][0]))
+            if not np.isfinite(solution):
+                raise ControllerSolverError("solve() failed with objective: '%s', and status: %s" % (solution, status))
+            self._solution = out["v"][0].reshape(-1, 1)
+            self._status = status
+            return solution
+        finally:
+            self._solve_time_overall = time.time() - start
+
+    def feedback(self, k, x_k=None, omega_tilde_k=None, external_solve=None, **kwargs):
+        self.solve(k=k, x_k=x_k, omega_tilde_k=omega_tilde_k, external_solve=external_solve, **kwargs)
+        return self.variables_k
+
+    @property
+    def variables_k(self):
+        """step-k slices {x,u,delta,z,mu,v,y,omega} as column vectors (variables.py:75-85)"""
+        info = self.mld_info_k
+        out = dict(x=self._x_k, omega=self._omega_tilde_k[:info.nomega])
+        if self._solution is None:
+            return out
+        v = self._solution[:info.nv]
+        o1, o2, o3 = info.nu, info.nu + info.ndelta, info.nu + info.ndelta + info.nz
+        out.update(v=v, u=v[:o1], delta=v[o1:o2], z=v[o2:o3], mu=v[o3:])
+        m = self._model
+        out["y"] = (m["C"] @ out["x"] + m["D1"] @ out["u"] + m["D2"] @ out["delta"] + m["D3"] @ out["z"]
+                    + m["D4"] @ out["omega"] + m["d5"])
+        return out
+
+    @property
+    def v_N_tilde(self):
+        return self._solution
+
+    def predicted_trajectory(self):
+        """x_N_tilde and y_N_tilde of the last solution (variables.py:259-275) from the K1/K2 matrices"""
+        evo = self.mld_evo_matrices
+        s, o = evo.state_input, evo.output
+        x = s["Phi_x_N_tilde"] @ self._x_k + s["Gamma_v_N_tilde"] @ self._solution + \
+            s["Gamma_omega_N_tilde"] @ self._omega_tilde_k + s["Gamma_5_N_tilde"]
+        y = o["L_x_N_tilde"] @ self._x_k + o["L_v_N_tilde"] @ self._solution + \
+            o["L_omega_N_tilde"] @ self._omega_tilde_k + o["L_5_N_tilde"]
+        return x, y
+
+    def sim_step_k(self, k, x_k=None, u_k=None, omega_k=None, mld_numeric_k=None, solver=None, step_state=True):
+        """controller_base.py:229-253 with the MPC's own delta/z/mu (no auxiliary MIP)"""
+        var_k = self.variables_k
+        omega_k = omega_k if omega_k is not None else var_k["omega"]
+        x_k = x_k if x_k is not None else var_k["x"]
+        sim_model = mld_numeric_k if mld_numeric_k is not None else self._model
+        lsim_k = sim_model.lsim_k(x_k=x_k, u_k=u_k if u_k is not None else var_k.get("u"), delta_k=var_k.get("delta"),
+                                  z_k=var_k.get("z"), mu_k=var_k.get("mu"), omega_k=omega_k)
+        if step_state:
+            lsim_k.update({name + "_hat": val for name, val in var_k.items()})
+            self._sim_log.set_sim_k(k=k, sim_k=lsim_k)
+            self._sim_log.update_sim_k(k=k, time_solve_overall=self._solve_time_overall,
+                                       time_in_solver=self._solve_time_solver)
+            self.x_k = lsim_k["x_k1"]
+        else:
+            del lsim_k["x_k1"]
+        return lsim_k

@@ -135,8 +135,9 @@ class MldModel(object):
                  nx=rows(STATE_INPUT_MATS), ny=rows(OUTPUT_MATS),
                  nu=cols(("B1", "D1", "F1")), ndelta=cols(("B2", "D2", "F2")), nz=cols(("B3", "D3", "F3")),
                  nomega=cols(("B4", "D4", "F4")), nmu=cols(("Psi",)))
-        d["nv"] = max(sum(shapes[n][1] for n in ("B1", "B2", "B3")), sum(shapes[n][1] for n in ("D1", "D2", "D3")),
-                      sum(shapes[n][1] for n in ("F1", "F2", "F3", "Psi")))
+        # the reference takes the max of the three hstack widths *before* padding (mld_model.py:163-166), which
+        # under-counts when e.g. F1 is omitted; nv is defined here as the width v = [u;delta;z;mu] really has
+        d["nv"] = d["nu"] + d["ndelta"] + d["nz"] + d["nmu"]
         return d
 
     @staticmethod

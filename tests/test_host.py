@@ -1,0 +1,111 @@
+"""Host-side mirror (no GPU): MldModel / MldInfo rules, objective-atom parsing and tiling against the
+reference's golden vectors, controller error behaviour, C-ABI export surface."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _golden as g
+import condense_np as cn
+import pyhybridcontrol_amd as phc
+from pyhybridcontrol_amd import _lib, host, objective_atoms as oa_mod, synthetic as syn
+
+
+@pytest.mark.parametrize("path", g.case_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_mld_model_dims_and_types_match_reference(path):
+    z, mats, dims, N_p, N_t = g.load_case(path)
+    given = {k: v for k, v in mats.items() if v.size}
+    if "C" not in given:
+        given["C"] = mats["C"].reshape(dims["ny"], dims["nx"])
+    m = phc.MldModel(given, nu_l=dims["nu_l"], nmu_l=dims["nmu_l"], ts=1)
+    info = m.mld_info
+    for k in ("nx", "nu", "ndelta", "nz", "nmu", "nomega", "ny", "n_constraints", "nu_l", "ndelta_l", "nz_l", "nmu_l", "nv_l"):
+        assert info[k] == dims[k], (k, info[k], dims[k])
+    assert info["nv"] == dims["nu"] + dims["ndelta"] + dims["nz"] + dims["nmu"]
+    assert [str(t) for t in info["var_type_v"].ravel()] == [str(t) for t in z["var_type_v"]]
+    for name in g.MATS:        # zero padding to (sys_dim, var_dim)
+        if mats[name].size:
+            assert np.array_equal(m[name], mats[name])
+
+
+def test_mld_model_shape_errors_and_defaults():
+    with pytest.raises(ValueError, match="must be a square matrix"):
+        phc.MldModel(A=np.zeros((2, 3)))
+    with pytest.raises(ValueError, match="Invalid matrix name"):
+        phc.MldModel({"Q": [[1.0]]})
+    with pytest.raises(ValueError, match="dimension"):
+        phc.MldModel(A=np.eye(2), B1=np.zeros((3, 1)))
+    with pytest.raises(ValueError, match="f5"):
+        phc.MldModel(A=np.eye(1), E=[[1.0]])
+    m = phc.MldModel(A=[[0.5]], B1=[[1.0]])
+    assert np.array_equal(m.C, np.eye(1)) and m.mld_info.ny == 1           # C defaults to I
+    assert m.D1.shape == (1, 1) and not m.D1.any() and m.F1.shape == (0, 1)
+    with pytest.raises(ValueError):
+        m.A[0, 0] = 1.0                                                     # read-only like the reference
+    out = m.lsim_k(x_k=[2.0], u_k=[1.0])
+    assert out["x_k1"][0, 0] == 2.0 and out["y"][0, 0] == 2.0
+
+
+def test_objective_atoms_match_reference_weights():
+    z = np.load(os.path.join(g.GDIR, "ref_objective_weights.npz"))
+    dims = dict(nx=1, nu=1, ndelta=0, nz=0, nmu=2, nomega=1, ny=1, nc=2)
+    tags = sorted({k.split("|")[0] for k in z.files if "|" in k and not k.startswith("spec")})
+    for tag in tags:
+        spec = {str(k): z["specval_%s|%s" % (tag, k)] for k in z["spec_" + tag]}
+        atoms = phc.ObjectiveAtoms(dims, 4, 5, spec)
+        ref_keys = [k for k in z.files if k.startswith(tag + "|")]
+        assert len(atoms.weights) == len(ref_keys)
+        for (var, atype, wtype, rate), w in atoms.weights.items():
+            assert np.allclose(w, z["%s|%s|%s_%s%s" % (tag, var, atype, wtype, "_d" if rate else "")], rtol=0, atol=1e-14)
+
+
+def test_objective_atom_parsing_rules_and_errors():
+    assert oa_mod.parse_key("q_mu") == ("vector", "Linear", "mu", False, "")
+    assert oa_mod.parse_key("Q_x_f") == ("matrix", "Quadratic", "x", False, "f")
+    assert oa_mod.parse_key("q_Quadratic_y_N_p") == ("vector", "Quadratic", "y", False, "N_p")
+    assert oa_mod.parse_key("q_L1_du") == ("vector", "L1", "u", True, "")
+    assert oa_mod.parse_key("q_delta")[2:4] == ("delta", False)              # 'delta' is not a rate of 'elta'
+    with pytest.raises(ValueError, match="is not valid"):
+        oa_mod.parse_key("q_foo")
+    dims = dict(nx=1, nu=1, ndelta=0, nz=0, nmu=2, nomega=1, ny=1, nc=2)
+    with pytest.raises(NotImplementedError):
+        phc.ObjectiveAtoms(dims, 2, 3, {"q_L1_u": 1.0}).to_cost()
+    with pytest.raises(NotImplementedError):
+        phc.ObjectiveAtoms(dims, 2, 3, {"q_du": 1.0}).to_cost()
+    assert not phc.ObjectiveAtoms(dims, 2, 3, {"q_u": 0.0}).weights           # all-zero weights are dropped
+
+
+def test_cost_tiling_matches_oracle_assembly():
+    wl = syn.make_workload("cfg2", batch=1, quadratic=True)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    c = host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"])
+    sf = cn.standard_form(ag["mats"], ag["atoms"], wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
+    evo = sf["evo"]
+    Ws = c["quad_x"] + c["quad_x"].T
+    q0 = c["lin_v"] + evo["Gamma_v"].T @ c["lin_x"] + (evo["Gamma_v"].T @ Ws @ evo["Gamma_5"])[:, 0]
+    assert np.allclose(q0, sf["cost"]["q0"], rtol=0, atol=1e-12)
+    assert np.allclose(evo["Gamma_v"].T @ Ws @ evo["Gamma_v"], sf["cost"]["P"], rtol=0, atol=1e-12)
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mldgpu.h")).read()
+    declared = set(re.findall(r"\b(mld_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"mld_err", "mld_status"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert "mldgpu" in _lib.version()
+
+
+def test_no_cpu_fallback_without_a_device():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    m = phc.MldModel(A=[[0.9]], B1=[[1.0]], E=[[1.0]], F1=[[0.0]], f5=[[10.0]], nu_l=1)
+    ctrl = phc.MpcController(m, N_p=2)
+    with pytest.raises(phc.ControllerBuildRequiredError):
+        ctrl.solve(0, x_k=[1.0])
+    with pytest.raises(phc.MldGpuError, match="no HIP device"):
+        ctrl.build()

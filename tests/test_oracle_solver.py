@@ -1,0 +1,113 @@
+"""The oracle's exact MILP solver (oracle/mld_oracle.c): there is NO reference fixture for the solve (the
+reference has no tests and delegates to Gurobi) -> "parity unpinned" at the solver boundary.  It is pinned here
+against (a) exhaustive enumeration of the binaries, (b) scipy's HiGHS (independent third-party MILP solver),
+(c) the known-answer instance recorded in SURVEY.md section 8c."""
+import numpy as np
+import pytest
+from scipy.optimize import milp, LinearConstraint, Bounds
+
+import condense_np as cn
+import orc
+import tighten_np
+import bnc_np
+from pyhybridcontrol_amd import synthetic as syn
+
+
+def _instance(name, s=0, batch=4, tight=False, agent=0):
+    wl = syn.make_workload(name, batch=batch)
+    ag = wl["agents"][agent]
+    d = ag["dims"]
+    mats = tighten_np.tighten(ag["mats"], d, nu_l=d["nu_l"]) if tight else ag["mats"]
+    sf = cn.standard_form(mats, ag["atoms"], wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
+    h = cn.rhs(sf["evo"], ag["x0"][s], ag["omega"][s])
+    q = cn.lin_cost(sf["cost"], ag["x0"][s], ag["omega"][s])
+    return sf, q, h
+
+
+def _highs(sf, q, h):
+    lb = np.where(np.isinf(sf["lb"]), -1e7, sf["lb"])
+    ub = np.where(np.isinf(sf["ub"]), 1e7, sf["ub"])
+    r = milp(q, constraints=LinearConstraint(sf["G"], -np.inf, h), integrality=sf["is_bin"].astype(int),
+             bounds=Bounds(lb, ub), options=dict(mip_rel_gap=0))
+    assert r.status == 0
+    return r.fun
+
+
+def test_known_answer_dewh_survey_8c():
+    """DEWH, N_tilde=5, x0=50.3, omega=[.004,.012,0,.009,.002], price [1,3,3,1,1] => u*=[1,0,0,1,0], objective 1.5"""
+    mats = dict(A=[[0.9970371127900564]], B1=[[4.298192277481107]], B4=[[-179.73320827515]], b5=[[0.07407218024859108]],
+                E=[[1], [-1]], F1=[[0], [0]], Psi=[[-1, 0], [0, -1]], f5=[[65.0], [-50.0]], C=[[1.0]])
+    mats = {k: np.array(v, dtype=float) for k, v in mats.items()}
+    price = np.array([1, 3, 3, 1, 1.0])
+    atoms = dict(q_u=(price * 0.75).reshape(-1, 1), q_mu=[90.0, 90.0])
+    sf = cn.standard_form(mats, atoms, 4, 5, nu_l=1)
+    h = cn.rhs(sf["evo"], [50.3], [.004, .012, 0, .009, .002])
+    q = cn.lin_cost(sf["cost"], [50.3], [.004, .012, 0, .009, .002])
+    r = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"])
+    assert r["status"] == "optimal"
+    u = r["x"].reshape(5, 3)[:, 0]
+    assert np.array_equal(u, [1, 0, 0, 1, 0])
+    assert abs(r["obj"] - 1.5) < 1e-9
+    e = orc.enumerate_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"])
+    assert abs(e["obj"] - 1.5) < 1e-9
+    p = bnc_np.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"])
+    assert p["status"] == "optimal" and abs(p["obj"] - 1.5) < 1e-9
+
+
+@pytest.mark.parametrize("s", range(4))
+def test_cfg1_matches_enumeration(s):
+    sf, q, h = _instance("cfg1", s)
+    r = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"])
+    e = orc.enumerate_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"])
+    assert r["status"] == e["status"] == "optimal"
+    assert abs(r["obj"] - e["obj"]) <= 1e-8 * max(1, abs(e["obj"]))
+
+
+def test_random_small_milps_match_enumeration_and_highs():
+    rng = np.random.Generator(np.random.PCG64(11))
+    solved = 0
+    for t in range(25):
+        n, m, nb = 9, 7, 6
+        G = rng.standard_normal((m, n)) * (rng.random((m, n)) < 0.7)
+        xf = rng.random(n)
+        h = G @ xf + rng.random(m)              # feasible for the relaxation at xf
+        q = rng.standard_normal(n)
+        lb = np.zeros(n)
+        ub = np.concatenate([np.ones(nb), np.full(n - nb, 5.0)])
+        is_bin = np.arange(n) < nb
+        r = orc.solve_milp(q, G, h, lb, ub, is_bin)
+        e = orc.enumerate_milp(q, G, h, lb, ub, is_bin)
+        assert r["status"] == e["status"], t
+        if e["status"] == "optimal":
+            assert abs(r["obj"] - e["obj"]) <= 1e-7 * max(1, abs(e["obj"])), t
+            hi = milp(q, constraints=LinearConstraint(G, -np.inf, h), integrality=is_bin.astype(int), bounds=Bounds(lb, ub))
+            assert abs(hi.fun - e["obj"]) <= 1e-6 * max(1, abs(e["obj"]))
+            xs = r["x"]
+            assert np.all(G @ xs <= h + 1e-7) and np.all((xs[is_bin] == 0) | (xs[is_bin] == 1))
+            solved += 1
+    assert solved >= 10
+
+
+@pytest.mark.parametrize("s", range(3))
+def test_cfg2_matches_highs_and_tightening_keeps_the_optimum(s):
+    sf0, q0, h0 = _instance("cfg2", s, tight=False)
+    ref = _highs(sf0, q0, h0)
+    sf, q, h = _instance("cfg2", s, tight=True)
+    r = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], max_nodes=50000, presolve=0)
+    assert r["status"] == "optimal"
+    assert abs(r["obj"] - ref) <= 1e-5 * max(1, abs(ref))
+    # the returned point is feasible for the ORIGINAL (un-tightened) rows with the same cost
+    x = r["x"]
+    rown = np.maximum(1, np.abs(sf0["G"]).max(axis=1))
+    assert np.all((sf0["G"] @ x - h0) / rown <= 1e-6)
+    assert abs(q0 @ x - r["obj"]) <= 1e-9 * max(1, abs(ref))
+
+
+def test_infeasible_and_node_limit_statuses():
+    G = np.array([[1.0, 1.0], [-1.0, -1.0]])
+    h = np.array([0.5, -1.5])                    # x1+x2 <= .5 and >= 1.5
+    r = orc.solve_milp(np.ones(2), G, h, np.zeros(2), np.ones(2), np.array([True, True]))
+    assert r["status"] == "infeasible" and not np.isfinite(r["obj"])
+    sf, q, h = _instance("cfg2", 0, tight=False)
+    r = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], max_nodes=3, presolve=0)
+    assert r["status"] in ("node_limit", "optimal")
