@@ -147,6 +147,10 @@ int mld_solve_resident(mld_problem_t *, mld_stats *stats_out);
 int mld_download_results(mld_problem_t *, double *v_out, double *obj_out, int32_t *status_out,
                          double *lower_bound_out, int32_t *nodes_out, int32_t *pivots_out);
 
+/* Per-instance telemetry of the last solve: time spent inside the solve kernel (device wall clock, ns) and
+ * the number of dictionary rows the rank-1 updates touched (x *row_bytes x 2 = bytes streamed by pivots). */
+int mld_download_telemetry(mld_problem_t *, int64_t *latency_ns, int64_t *rows_updated, int64_t *row_bytes);
+
 /* Constraint right-hand side only (kernel K3): h = H_x x_k + H_w w + H_5 per instance
  * (controllers/controller_base.py:446-450); `scenarios`>1 applies the row-min over scenario columns
  * of H_w Omega (:442-444) with omega laid out (batch, scenarios, N_tilde*nomega).  h_out (batch, N nc).

@@ -677,7 +677,7 @@ int orc_solve_milp(int n, int m, const double *q, const double *G, const double 
          * (finds an optimal vertex of the optimal face quickly when the root bound is tight), grows
          * geometrically while no incumbent exists and becomes +inf once one does. */
         const double root_bound = st->root_bound;
-        int nodes = 0, limit = 0, pass = 0;
+        int nodes = 0, limit = 0, pass = 0, rescue = 0, node_budget = o->max_nodes;
         double T = root_bound + fmax(1e-7 * fmax(1.0, fabs(root_bound)), gtol(o, root_bound));
         status = ORC_NODE_LIMIT;
         for (;;) {
@@ -727,8 +727,8 @@ int orc_solve_milp(int n, int m, const double *q, const double *G, const double 
                         }
                     }
                 }
-                if (have && best <= root_bound + gtol(o, best)) { finished = 1; }
-                if (nodes >= o->max_nodes) limit = 1;
+                if (have && (rescue || best <= root_bound + gtol(o, best))) { finished = 1; }
+                if (nodes >= node_budget) limit = 1;
                 if (branch_j >= 0 && !limit && !finished) {
                     const double first = branch_x >= 0.5 ? 1.0 : 0.0;
                     stk_j[depth] = branch_j; stk_first[depth] = first; stk_second[depth] = 0; depth++;
@@ -742,8 +742,12 @@ int orc_solve_milp(int n, int m, const double *q, const double *G, const double 
                 stk_second[depth - 1] = 1;
                 { const int j = stk_j[depth - 1]; const double v = 1.0 - stk_first[depth - 1]; set_bounds(t, j, v, v); }
             }
-            if (finished) { status = ORC_OPTIMAL; break; }
-            if (limit) break;
+            if (finished) { if (!rescue) status = ORC_OPTIMAL; break; }
+            if (limit) {
+                /* node limit without an incumbent: one un-thresholded dive so that a feasible point is returned */
+                if (!have && !rescue && lp != LP_ITERLIMIT) { rescue = 1; limit = 0; T = INFINITY; node_budget = nodes + 3 * nb + 10; continue; }
+                break;
+            }
             /* the pass was exhaustive for its threshold */
             if (have && best - gtol(o, best) <= T) { status = ORC_OPTIMAL; break; }
             if (!isfinite(t_next)) { status = have ? ORC_OPTIMAL : ORC_INFEASIBLE; break; }

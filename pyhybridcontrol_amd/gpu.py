@@ -202,6 +202,15 @@ class GpuProblem(object):
                                                ip(nodes), ip(pivots)))
         return dict(v=v, obj=obj, status=status, lower_bound=lbnd, nodes=nodes, pivots=pivots)
 
+    def telemetry(self):
+        """per-instance in-kernel latency (ns) and dictionary rows updated; row_bytes = bytes per row"""
+        b = self.batch
+        lat, rows = np.zeros(b, np.int64), np.zeros(b, np.int64)
+        rb = C.c_int64()
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+        check(_lib.load().mld_download_telemetry(self._h, ip(lat), ip(rows), C.byref(rb)))
+        return dict(latency_ns=lat, rows_updated=rows, row_bytes=int(rb.value))
+
     def solve(self, x0, omega, model_idx=None, fixed_bin=None):
         self.upload(x0, omega, model_idx, fixed_bin)
         stats = self.solve_resident()

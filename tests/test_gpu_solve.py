@@ -48,3 +48,186 @@ def test_solve_matches_oracle(name, nb):
         assert abs(out["obj"][s] - (ref["obj"] + r)) <= 1e-6 * max(1.0, abs(ref["obj"] + r)), (s, out["obj"][s], ref["obj"] + r)
         check_solution(ag, wl, s, out["v"][s], out["obj"][s])
     p.close(); m.close()
+
+
+def test_cfg3_multi_model_batch_matches_oracle_or_reports_limit():
+    """three distinct agents x 4 scenarios in one launch (model_idx), cfg3 shape, full branch-and-bound"""
+    wl = syn.make_workload("cfg3", batch=4, n_agents=3)
+    d = wl["agents"][0]["dims"]
+    m = gpu.GpuModel([a["mats"] for a in wl["agents"]], d)
+    cost = host.stack_costs([host.cost_from_atoms(a["atoms"], d, wl["N_p"], wl["N_tilde"]) for a in wl["agents"]])
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost, max_nodes=3000)
+    x0 = np.concatenate([a["x0"] for a in wl["agents"]])
+    om = np.concatenate([a["omega"] for a in wl["agents"]])
+    midx = np.repeat(np.arange(3), 4).astype(np.int32)
+    out = p.solve(x0, om, midx)
+    n_opt = 0
+    for i in range(12):
+        a, s = wl["agents"][i // 4], i % 4
+        st = gpu._lib.STATUS_NAMES[int(out["status"][i])]
+        assert st in ("optimal", "node_limit")
+        if np.isfinite(out["obj"][i]):
+            check_solution(a, wl, s, out["v"][i], out["obj"][i])
+            assert out["lower_bound"][i] <= out["obj"][i] + 1e-6
+        if st == "optimal":
+            sf, q, h, r = _oracle_instance(a, wl, s)
+            ref = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], max_nodes=50000, presolve=0)
+            if ref["status"] == "optimal":
+                assert abs(out["obj"][i] - (ref["obj"] + r)) <= 1e-6 * max(1.0, abs(ref["obj"] + r)), i
+                n_opt += 1
+    assert n_opt >= 6
+    p.close(); m.close()
+
+
+def test_relaxation_only_mode_with_fixed_binaries():
+    """BASELINE cfg2: binaries fixed -> one LP per instance (no branching); equals the oracle's LP"""
+    wl = syn.make_workload("cfg2", batch=8)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    m = gpu.GpuModel([ag["mats"]], d)
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"]))
+    rng = np.random.Generator(np.random.PCG64(5))
+    nb = p.n_bin
+    fixed = np.zeros((8, nb), dtype=np.uint8)
+    bins = np.where(p.is_bin)[0]
+    isdelta = (bins % m.nv) == d["nu"]
+    for s in range(8):
+        om = ag["omega"][s].reshape(wl["N_tilde"], -1)
+        u = (rng.random((wl["N_tilde"], d["nu"])) < 0.2).astype(np.uint8)
+        y = u @ ag["params"]["P_h_Nom"] + om[:, -1]
+        dl = (y >= 0).astype(np.uint8)                       # delta consistent with the sign of y
+        fixed[s, ~isdelta] = u.ravel()
+        fixed[s, isdelta] = dl
+    out = p.solve(ag["x0"], ag["omega"], fixed_bin=fixed)
+    for s in range(8):
+        sf, q, h, r = _oracle_instance(ag, wl, s)
+        lb, ub = sf["lb"].copy(), sf["ub"].copy()
+        lb[bins] = ub[bins] = fixed[s]
+        ref = orc.solve_milp(q, sf["G"], h, lb, ub, np.zeros_like(sf["is_bin"]), presolve=0, max_cuts=0, cut_rounds=0)
+        assert gpu._lib.STATUS_NAMES[int(out["status"][s])] == ref["status"]
+        if ref["status"] == "optimal":
+            assert out["nodes"][s] == 1
+            assert abs(out["obj"][s] - (ref["obj"] + r)) <= 1e-6 * max(1.0, abs(ref["obj"]))
+            assert np.array_equal(out["v"][s][bins], fixed[s])
+            check_solution(ag, wl, s, out["v"][s], out["obj"][s])
+    p.close(); m.close()
+
+
+def test_rhs_kernel_matches_oracle_including_scenario_row_min():
+    wl = syn.make_workload("cfg2", batch=5, n_agents=2)
+    d = wl["agents"][0]["dims"]
+    m = gpu.GpuModel([a["mats"] for a in wl["agents"]], d)
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], None)
+    x0 = np.concatenate([a["x0"] for a in wl["agents"]])
+    om = np.concatenate([a["omega"] for a in wl["agents"]])
+    midx = np.repeat(np.arange(2), 5).astype(np.int32)
+    h = p.rhs(x0, om, midx)
+    for i in range(10):
+        a = wl["agents"][i // 5]
+        evo = cn.condense(a["mats"], wl["N_tilde"])
+        ref = cn.rhs(evo, x0[i], om[i])
+        assert np.abs(h[i] - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    # scenario form: row-min over scenario columns of H_omega @ Omega (controller_base.py:442-444)
+    a = wl["agents"][0]
+    evo = cn.condense(a["mats"], wl["N_tilde"])
+    Om = a["omega"][:4]                                    # 4 scenarios, as columns
+    hs = p.rhs(a["x0"][:1], Om[np.newaxis], np.zeros(1, np.int32), scenarios=4)
+    ref = cn.rhs_scenarios(evo, a["x0"][0], Om.T)
+    assert np.abs(hs[0] - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    p.close(); m.close()
+
+
+def test_cost_assembly_kernel_matches_oracle_with_quadratic_atoms():
+    wl = syn.make_workload("cfg2", batch=1, quadratic=True)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    atoms = dict(ag["atoms"])
+    atoms["q_Quadratic_y"] = 1e-4
+    atoms["Q_u"] = 0.5 * np.eye(d["nu"])
+    atoms["q_x"] = np.linspace(0.1, 0.3, d["nx"])
+    m = gpu.GpuModel([ag["mats"]], d)
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], host.cost_from_atoms(atoms, d, wl["N_p"], wl["N_tilde"]))
+    got = p.cost_assemble()
+    sf = cn.standard_form(ag["mats"], atoms, wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
+    for k in ("P", "q0", "Qx", "Qw"):
+        ref = sf["cost"][k]
+        assert np.abs(got[k][0] - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), k
+    with pytest.raises(gpu.MldGpuError, match="linear cost only"):
+        p.solve(ag["x0"], ag["omega"])
+    p.close(); m.close()
+
+
+def test_mpc_controller_end_to_end_known_answer():
+    """the reference's call sequence: set_std_obj_atoms -> build -> solve/feedback -> sim_step_k (SURVEY 8c KAT)"""
+    import pyhybridcontrol_amd as phc
+    model = phc.MldModel(A=[[0.9970371127900564]], B1=[[4.298192277481107]], B4=[[-179.73320827515]],
+                         b5=[[0.07407218024859108]], E=[[1], [-1]], F1=[[0], [0]], Psi=[[-1, 0], [0, -1]],
+                         f5=[[65.0], [-50.0]], nu_l=1, ts=900)
+    ctrl = phc.MpcController(model, N_p=4)
+    assert ctrl.N_tilde == 5
+    with pytest.raises(phc.ControllerBuildRequiredError):
+        ctrl.solve(0, x_k=[50.3])
+    price = np.array([1, 3, 3, 1, 1.0])
+    ctrl.set_std_obj_atoms(q_u=(price * 0.75).reshape(-1, 1), q_mu=[90.0, 90.0])
+    ctrl.build()
+    obj = ctrl.solve(0, x_k=[50.3], omega_tilde_k=[.004, .012, 0, .009, .002])
+    assert abs(obj - 1.5) < 1e-9
+    assert np.array_equal(ctrl.v_N_tilde.reshape(5, 3)[:, 0], [1, 0, 0, 1, 0])
+    vk = ctrl.feedback(0)
+    assert vk["u"].shape == (1, 1) and vk["u"][0, 0] == 1.0 and vk["mu"].shape == (2, 1)
+    x, y = ctrl.predicted_trajectory()
+    evo = cn.condense(model.as_mats(), 5)
+    assert np.allclose(ctrl.mld_evo_matrices.constraint["H_v_N_tilde"], evo["H_v"], rtol=0, atol=1e-12)
+    assert ctrl.mld_evo_matrices.state_input["Gamma_v_N_p"].shape == (4, 15)
+    cons = ctrl.gen_evo_constraints()
+    assert np.all(cons.H_v @ ctrl.v_N_tilde <= cons.rhs + 1e-9)
+    assert np.all(x[:, 0] >= 50.0 - 1e-6)
+    sim = ctrl.sim_step_k(0)
+    assert abs(sim["x_k1"][0, 0] - x[1, 0]) < 1e-9 and 0 in ctrl.sim_log
+    assert ctrl.x_k[0, 0] == sim["x_k1"][0, 0]
+    assert ctrl._solve_time_overall > 0 and ctrl._solve_time_solver > 0
+    assert ctrl.solve(1, external_solve=7.0) == 7.0            # external_solve bypass (controller_base.py:536-538)
+    ctrl.set_std_obj_atoms(q_u=price.reshape(-1, 1), q_mu=[90.0, 90.0])
+    with pytest.raises(phc.ControllerBuildRequiredError):
+        ctrl.solve(1)
+    ctrl.build(sense="maximize")
+    assert np.isfinite(ctrl.solve(1, MIPGap=1e-2))
+    # an infeasible instance -> ControllerSolverError (hard bound instead of the soft one)
+    hard = phc.MldModel(A=[[1.0]], B1=[[0.0]], E=[[1.0], [-1.0]], F1=[[0.0], [0.0]], f5=[[1.0], [-2.0]], nu_l=1)
+    c2 = phc.MpcController(hard, N_p=1)
+    c2.set_std_obj_atoms(q_u=1.0)
+    c2.build()
+    with pytest.raises(phc.ControllerSolverError):
+        c2.solve(0, x_k=[0.0])
+
+
+def test_full_size_batch_properties_cfg3():
+    """BASELINE cfg3 at full batch (1024): size-independent properties instead of per-instance oracle solves:
+    every returned point is integer feasible for the original rows with the reported cost, lower bound <=
+    objective, a second solve is bit-identical (idempotence), and solving the two halves separately returns
+    the same per-instance results (sharding must not change any instance's arithmetic)."""
+    wl = syn.make_workload("cfg3", batch=1024)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    m = gpu.GpuModel([ag["mats"]], d)
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"]),
+                       max_nodes=300)
+    out = p.solve(ag["x0"], ag["omega"])
+    fin = np.isfinite(out["obj"])
+    assert fin.mean() > 0.97 and (out["status"] == 0).mean() > 0.5
+    sf = cn.standard_form(ag["mats"], ag["atoms"], wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
+    G, bins = sf["G"], sf["is_bin"]
+    rown = np.maximum(1.0, np.abs(G).max(axis=1))
+    H = np.stack([cn.rhs(sf["evo"], ag["x0"][s], ag["omega"][s]) for s in range(1024)])
+    V = out["v"]
+    assert np.all(((V[fin][:, bins] == 0) | (V[fin][:, bins] == 1)))
+    assert np.all((V[fin] @ G.T - H[fin]) / rown <= 1e-6)
+    assert np.all(np.abs(V[fin] @ sf["cost"]["q0"] - out["obj"][fin]) <= 1e-6 * np.maximum(1, np.abs(out["obj"][fin])))
+    assert np.all(out["lower_bound"][fin] <= out["obj"][fin] + 1e-6)
+    out2 = p.solve(ag["x0"], ag["omega"])
+    assert np.array_equal(out2["v"], V) and np.array_equal(out2["obj"], out["obj"]) and np.array_equal(out2["status"], out["status"])
+    a = p.solve(ag["x0"][:512], ag["omega"][:512])
+    b = p.solve(ag["x0"][512:], ag["omega"][512:])
+    assert np.array_equal(np.concatenate([a["obj"], b["obj"]]), out["obj"])
+    assert np.array_equal(np.concatenate([a["v"], b["v"]]), V)
+    p.close(); m.close()
