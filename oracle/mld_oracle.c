@@ -456,6 +456,8 @@ static int dual_simplex(dict_t *t, double cutoff)
             const int el = below ? (t->at_upper[c] ? a > 0 : a < 0) : (t->at_upper[c] ? a < 0 : a > 0);
             if (el && fabs(a) > emax) emax = fabs(a);
         }
+        /* every eligible entry above the absolute floor takes part in the ratio test (excluding entries that are
+           merely small RELATIVE to the row maximum lets their reduced costs change sign by O(1)) */
         const double ptol = fmax(ORC_PIV_ABS, ORC_PIV_REL * emax);
         double tmax = INFINITY, rmin = INFINITY;
         int any = 0;
@@ -592,6 +594,7 @@ static int gmi_round(dict_t *t, int max_cuts)
         double nrm = 0;
         for (int j = 0; j < n; ++j) if (fabs(ax[j]) > nrm) nrm = fabs(ax[j]);
         if (nrm <= 0) continue;
+        if (gmax > nrm) nrm = gmax;   /* keep the dictionary row (coefficients g) O(1) as well as the structural row */
         const int k = m_start + added;
         double *gk = t->Gx + (size_t)k * n, *dk = t->D + (size_t)k * ld;
         double s_now = bx / nrm, dx = 0;
@@ -655,20 +658,40 @@ int orc_solve_milp(int n, int m, const double *q, const double *G, const double 
     double *stk_first = dalloc(nb + 2);
     unsigned char *stk_second = (unsigned char *)calloc(nb + 2, 1);
     int *sv_j = (int *)calloc(nb + 2, sizeof(int)); double *sv_lo = dalloc(nb + 2), *sv_hi = dalloc(nb + 2);
-    int lp = dual_simplex(t, INFINITY);
+    int lp = LP_OPTIMAL, root_ok = 0;
     st->nodes = 1;
-    if (lp != LP_OPTIMAL) { status = lp == LP_INFEASIBLE ? ORC_INFEASIBLE : ORC_NUMERICAL; goto done; }
-    st->root_lp = objective(t);
-    int stalled = 0;
-    for (int rnd = 0; rnd < o->cut_rounds; ++rnd) {
-        const double before = objective(t);
-        const int k = gmi_round(t, o->cuts_per_round);
-        if (!k) break;
-        st->cuts += k;
+    /* root LP + cut rounds; if the LP breaks down while cutting the root is rebuilt and solved without cuts */
+    for (int attempt = 0; attempt < 2 && !root_ok; ++attempt) {
+        const int use_cuts = attempt == 0 && o->cut_rounds > 0;
+        if (attempt) {
+            t->m = m;
+            reset_dictionary(t);
+            for (int c = 0; c < n; ++c) place(t, c);
+            refresh(t);
+        }
         lp = dual_simplex(t, INFINITY);
         if (lp != LP_OPTIMAL) { status = lp == LP_INFEASIBLE ? ORC_INFEASIBLE : ORC_NUMERICAL; goto done; }
-        if (objective(t) - before < 1e-6 * fmax(1.0, fabs(before))) { if (++stalled >= 2) break; } else stalled = 0;
+        if (!attempt) st->root_lp = objective(t);
+        root_ok = 1;
+        st->cuts = 0;
+        if (use_cuts) {
+            int stalled = 0;
+            const long saved_cap = t->max_pivots;
+            for (int rnd = 0; rnd < o->cut_rounds; ++rnd) {
+                const double before = objective(t);
+                const int k = gmi_round(t, o->cuts_per_round);
+                if (!k) break;
+                st->cuts += k;
+                const long cap = t->pivots + 4L * m + 200;
+                t->max_pivots = cap < saved_cap ? cap : saved_cap;
+                lp = dual_simplex(t, INFINITY);
+                t->max_pivots = saved_cap;
+                if (lp != LP_OPTIMAL) { root_ok = 0; break; }
+                if (objective(t) - before < 1e-6 * fmax(1.0, fabs(before))) { if (++stalled >= 2) break; } else stalled = 0;
+            }
+        }
     }
+    if (!root_ok) { status = ORC_NUMERICAL; goto done; }
     st->root_bound = objective(t);
     memcpy(root_lo, t->lo, sizeof(double) * n); memcpy(root_hi, t->hi, sizeof(double) * n);
     {
@@ -692,6 +715,7 @@ int orc_solve_milp(int n, int m, const double *q, const double *G, const double 
                 const double inc_cut = have ? best - gtol(o, best) : INFINITY;
                 const double cut = fmin(T, inc_cut);
                 lp = dual_simplex(t, cut + 1e-12);
+                if (getenv("ORC_DEBUG")) fprintf(stderr, "node %d depth %d lp=%d obj=%.12g cut=%.12g T=%.12g\n", nodes, depth, lp, objective(t), cut, T);
                 if (lp == LP_ITERLIMIT) limit = 1;
                 else if (lp == LP_OPTIMAL || lp == LP_CUTOFF) {
                     const double obj = objective(t);
@@ -750,7 +774,15 @@ int orc_solve_milp(int n, int m, const double *q, const double *G, const double 
             }
             /* the pass was exhaustive for its threshold */
             if (have && best - gtol(o, best) <= T) { status = ORC_OPTIMAL; break; }
-            if (!isfinite(t_next)) { status = have ? ORC_OPTIMAL : ORC_INFEASIBLE; break; }
+            if (!isfinite(t_next)) {
+                if (!have && !rescue) {   /* every node "infeasible": re-derive the dictionary from the original rows and dive once more */
+                    refactor(t);
+                    rescue = 1; T = INFINITY; node_budget = nodes + 3 * nb + 10;
+                    continue;
+                }
+                status = have ? (rescue ? ORC_NODE_LIMIT : ORC_OPTIMAL) : ORC_INFEASIBLE;
+                break;
+            }
             if (have) T = INFINITY;
             else T = fmax(t_next + 1e-9 * fmax(1.0, fabs(t_next)), T + ldexp(2.5e-4, 2 * pass) * fmax(1.0, fabs(T)));
         }
