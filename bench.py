@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--mip-gap", type=float, default=1e-2, help="relative MIP gap; 1e-2 is the reference's own setting "
                     "(micro_grid_control_simulation.py:232 MIPGap=1e-2)")
     ap.add_argument("--node-limit", type=int, default=400, help="per-instance node limit (stands in for the reference's TimeLimit)")
+    ap.add_argument("--pivot-limit", type=int, default=20000, help="per-instance simplex iteration limit")
     ap.add_argument("--cpu-sample", type=int, default=24, help="instances timed with the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
@@ -66,7 +67,7 @@ def make_shard(n_agents, n_scen, scen_offset):
     return agents, N_p, N_t, x0.reshape(-1, nx), om.reshape(-1, nW), midx
 
 
-def cpu_baseline(agents, N_p, N_t, x0, om, midx, n_sample, gap, node_limit):
+def cpu_baseline(agents, N_p, N_t, x0, om, midx, n_sample, gap, node_limit, pivot_limit):
     """the C oracle (oracle/mld_oracle.c, kind "port") on the first n_sample instances, one host thread"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import condense_np as cn
@@ -86,7 +87,7 @@ def cpu_baseline(agents, N_p, N_t, x0, om, midx, n_sample, gap, node_limit):
         sf = forms[a]
         h = cn.rhs(sf["evo"], x0[i], om[i])
         q = cn.lin_cost(sf["cost"], x0[i], om[i])
-        r = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], gap_rel=gap, max_nodes=node_limit, presolve=0)
+        r = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], gap_rel=gap, max_nodes=node_limit, presolve=0, max_pivots=pivot_limit)
         t_total += time.perf_counter() - t0
         n_done += 1
         n_opt += r["status"] == "optimal"
@@ -115,7 +116,7 @@ def main():
     d = agents[0]["dims"]
     model = gpu.GpuModel([a["mats"] for a in agents], d)
     cost = host.stack_costs([host.cost_from_atoms(a["atoms"], d, N_p, N_t) for a in agents])
-    prob = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=args.mip_gap, max_nodes=args.node_limit)
+    prob = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit)
     n_local = x0.shape[0]
     prob.upload(x0, om, midx)                       # inputs resident in HBM before the timed region
     gatherer = None
@@ -156,7 +157,9 @@ def main():
     rows = int(tel["rows_updated"].sum())
     pivots = int(out["pivots"].sum())
     row_bytes = tel["row_bytes"]
-    upd_bytes = 2.0 * rows * row_bytes + pivots * (row_bytes + 8.0 * prob.m)   # rows read+written, pivot row, multiplier column
+    # bytes the simplex pivots stream: 64-byte sectors of the updated rows (read + write), the pivot row (read + write),
+    # the cost row (read + write) and the multiplier column (one 64-byte sector per row: it is a strided gather)
+    upd_bytes = 2.0 * rows * row_bytes + pivots * (2 * 8.0 * (prob.n + 1) + 2 * 8.0 * prob.n + 64.0 * prob.m)
     io_bytes = 8.0 * n_local * (prob.n + prob.m + d["nx"] + prob.nW)           # SURVEY 8d input/output minimum
     achieved = upd_bytes / (kernel_ms * 1e-3) / 1e9
     traffic = None
@@ -169,7 +172,8 @@ def main():
     lat = np.sort(tel["latency_ns"]) * 1e-6
     status = out["status"]
     fin = np.isfinite(out["obj"])
-    gap = np.where(fin, (out["obj"] - out["lower_bound"]) / np.maximum(1e-9, np.abs(out["obj"])), np.nan)
+    with np.errstate(invalid="ignore"):
+        gap = np.where(fin, (out["obj"] - out["lower_bound"]) / np.maximum(1e-9, np.abs(out["obj"])), np.nan)
     result = {
         "metric": "MPC steps/sec (whole node) + p50 solve latency, 64-agent microgrid N=24",
         "value": round(world * n_local * args.steps / elapsed, 2),
@@ -179,7 +183,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE cfg4 shard: %d agents x %d scenarios per GPU (n_h=7, N_p=24: n=575, 200 binaries, m=500), "
-                               "full branch-and-cut MILP, MIPGap=%g, NodeLimit=%d" % (args.agents, args.scenarios, args.mip_gap, args.node_limit),
+                               "full branch-and-cut MILP, MIPGap=%g, NodeLimit=%d, IterationLimit=%d" % (args.agents, args.scenarios, args.mip_gap, args.node_limit, args.pivot_limit),
                    "instances_per_gpu": n_local, "microgrid_steps_per_s": round(world * n_local * args.steps / elapsed / args.agents, 3),
                    "p50_solve_latency_ms": round(float(lat[len(lat) // 2]), 3), "p99_solve_latency_ms": round(float(lat[int(len(lat) * 0.99)]), 3),
                    "status": {"optimal": int((status == 0).sum()), "infeasible": int((status == 1).sum()),
@@ -203,7 +207,7 @@ def main():
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                        "bytes_per_model": int(bytes_cond), "models": args.agents, "kernel_ms": round(ms, 4)}
         if not args.no_cpu and args.cpu_sample > 0:
-            result["cpu_baseline"] = cpu_baseline(agents, N_p, N_t, x0, om, midx, args.cpu_sample, args.mip_gap, args.node_limit)
+            result["cpu_baseline"] = cpu_baseline(agents, N_p, N_t, x0, om, midx, args.cpu_sample, args.mip_gap, args.node_limit, args.pivot_limit)
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)

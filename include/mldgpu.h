@@ -55,11 +55,11 @@ typedef struct {
     double gap_abs;        /* absolute optimality tolerance (default 1e-9) */
     double gap_rel;        /* relative MIP gap (Gurobi MIPGap; default 0 = prove optimality) */
     int32_t max_nodes;     /* per instance (default 100000) */
-    int32_t max_pivots;    /* per instance simplex iteration limit (default 2000000) */
+    int32_t max_pivots;    /* per instance simplex iteration limit (default 50000) */
     int32_t cut_rounds;    /* Gomory mixed-integer cut rounds at the root (default 8) */
     int32_t cuts_per_round;/* default 40 */
     int32_t max_cuts;      /* rows reserved for cuts (default 200) */
-    int32_t presolve;      /* bit0: per-instance bound propagation, bit1: per-model big-M tightening (default 3) */
+    int32_t presolve;      /* bit1: per-model probing-based big-M tightening (default 2); bit0 reserved */
     int32_t n_slots;       /* resident workgroups (0 = auto: 2 per CU) */
     int32_t reserved;
 } mld_opts;
