@@ -410,7 +410,11 @@ static void refactor(dict_t *t)
         rowfree[br] = 0; want[bc] = 0;
     }
     t->pivots = saved;
-    for (int c = 0; c < n; ++c) { const int j = t->nonbasic[c]; t->xN[c] = val[j]; t->at_upper[c] = up[j]; }
+    for (int c = 0; c < n; ++c) {
+        const int j = t->nonbasic[c];
+        if (j < n && want[j]) place(t, c);   /* could not be pivoted in (numerically singular basis): park at a bound */
+        else { t->xN[c] = val[j]; t->at_upper[c] = up[j]; }
+    }
     refresh(t);
     free(want); free(rowfree); free(val); free(up);
 }
