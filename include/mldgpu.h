@@ -27,7 +27,7 @@ typedef enum {
     MLD_OK = 0,
     MLD_ERR_INVALID = -1,     /* bad argument / shape */
     MLD_ERR_NO_DEVICE = -2,   /* no HIP device: the product path has no CPU fallback */
-    MLD_ERR_UNSUPPORTED = -3, /* e.g. quadratic cost passed to the MILP solver */
+    MLD_ERR_UNSUPPORTED = -3, /* e.g. a problem too large for the LDS staging */
     MLD_ERR_HIP = -4,         /* HIP runtime error (text in mld_last_error) */
     MLD_ERR_COMM = -5         /* RCCL error */
 } mld_err;
@@ -71,8 +71,8 @@ typedef struct {
  *   lin_x  : N_tilde*nx   weight on x_tilde  (pulled back through Gamma_v: variables.py:259-265)
  *   lin_y  : N_tilde*ny   weight on y_tilde  (pulled back through L_v:     variables.py:269-275)
  * Quadratic weights (symmetric, full horizon size, NULL = none): quad_v (n x n), quad_x, quad_y --
- * cost  var' W var  (objective_atoms.py:321-331); they are assembled into P by mld_cost_assemble;
- * mld_solve_batch itself accepts linear cost only in this version. */
+ * cost  var' W var  (objective_atoms.py:321-331); they are assembled into P / Qx / Qw by kernel K4 and the
+ * solver then runs a convex-QP relaxation (simplicial decomposition) at every branch-and-bound node. */
 typedef struct {
     const double *lin_v, *lin_x, *lin_y;
     const double *quad_v, *quad_x, *quad_y;

@@ -234,6 +234,10 @@ typedef struct {
     long pivots, max_pivots;
     int refactors;
     double *tmp_col, *tmp_row;
+    /* convex-QP relaxations by simplicial decomposition (P != NULL) */
+    const double *P;      /* scaled Hessian n x n (NULL = linear cost) */
+    double *Y, *PY, *Hm, *cm, *wm, *gcost, *vcur, *Pv;
+    int pmax, qp_iters;
 } dict_t;
 
 static double *dalloc(size_t k) { return (double *)calloc(k + 1, sizeof(double)); }
@@ -498,6 +502,243 @@ static int dual_simplex(dict_t *t, double cutoff)
     }
 }
 
+
+/* ---- primal side: re-pricing with a new cost vector, bounded primal simplex, simplicial decomposition ----------- */
+#define LP_UNBOUNDED 4
+#define SD_PMAX 32
+
+/* reduced costs of the current basis for structural cost vector `cost` (slacks cost nothing) */
+static void reprice(dict_t *t, const double *cost)
+{
+    const int n = t->n, ld = t->ld;
+    double *d = t->D + (size_t)t->mcap * ld;
+    for (int c = 0; c <= n; ++c) d[c] = 0.0;
+    for (int c = 0; c < n; ++c) { const int j = t->nonbasic[c]; if (j < n) d[c] = cost[j]; }
+    for (int r = 0; r < t->m; ++r) {
+        const int j = t->basic[r];
+        if (j >= n || cost[j] == 0.0) continue;
+        const double cj = cost[j];
+        const double *row = t->D + (size_t)r * ld;
+        for (int c = 0; c < n; ++c) d[c] -= cj * row[c];
+        d[n] += cj * row[n];
+    }
+}
+
+/* bounded primal simplex from a primal-feasible basis (Dantzig pricing, Harris ratio test, Bland while stalling) */
+static int primal_simplex(dict_t *t)
+{
+    const int n = t->n, ld = t->ld, m = t->m;
+    const double *d = t->D + (size_t)t->mcap * ld;
+    int stall = 0;
+    double last_obj = INFINITY;
+    for (;;) {
+        if (t->pivots >= t->max_pivots) return LP_ITERLIMIT;
+        const double cur = objective(t);
+        if (cur < last_obj - 1e-12 * fmax(1.0, fabs(cur))) { stall = 0; last_obj = cur; } else stall++;
+        const int bland = stall > 30;
+        int c = -1; double best = ORC_DTOL; int bid = 0x7fffffff;
+        for (int k = 0; k < n; ++k) {
+            const int j = t->nonbasic[k];
+            if (t->lo[j] == t->hi[j]) continue;
+            const double viol = t->at_upper[k] ? d[k] : -d[k];
+            if (viol <= ORC_DTOL) continue;
+            if (bland) { if (j < bid) { bid = j; c = k; } }
+            else if (viol > best) { best = viol; c = k; }
+        }
+        if (c < 0) return LP_OPTIMAL;
+        const int jc = t->nonbasic[c];
+        const double dir = t->at_upper[c] ? -1.0 : 1.0;
+        /* pass 1: Harris bound */
+        double tmax = t->hi[jc] - t->lo[jc];
+        double amax = 0;
+        for (int i = 0; i < m; ++i) { const double a = fabs(t->D[(size_t)i * ld + c]); if (a > amax) amax = a; }
+        const double ptol = fmax(ORC_PIV_ABS, ORC_PIV_REL * amax);
+        for (int i = 0; i < m; ++i) {
+            const double a = t->D[(size_t)i * ld + c] * dir;
+            if (fabs(a) <= ptol) continue;
+            const int j = t->basic[i];
+            const double room = a > 0 ? t->xB[i] - t->lo[j] : t->hi[j] - t->xB[i];
+            const double r1 = (fmax(room, 0.0) + ORC_PTOL) / fabs(a);
+            if (r1 < tmax) tmax = r1;
+        }
+        /* pass 2: largest pivot among rows whose exact ratio is within the bound */
+        int r = -1; double abest = -1;
+        for (int i = 0; i < m; ++i) {
+            const double a = t->D[(size_t)i * ld + c] * dir;
+            if (fabs(a) <= ptol) continue;
+            const int j = t->basic[i];
+            const double room = a > 0 ? t->xB[i] - t->lo[j] : t->hi[j] - t->xB[i];
+            const double r0 = fmax(room, 0.0) / fabs(a);
+            if (r0 <= tmax && fabs(a) > abest) { abest = fabs(a); r = i; }
+        }
+        if (r < 0) {
+            const double range = t->hi[jc] - t->lo[jc];
+            if (!isfinite(range)) return LP_UNBOUNDED;
+            /* bound flip */
+            const double nw = t->at_upper[c] ? t->lo[jc] : t->hi[jc];
+            const double dl = nw - t->xN[c];
+            for (int i = 0; i < m; ++i) t->xB[i] -= t->D[(size_t)i * ld + c] * dl;
+            t->xN[c] = nw; t->at_upper[c] = !t->at_upper[c];
+            t->pivots++;
+            continue;
+        }
+        {
+            const int jr = t->basic[r];
+            const double a = t->D[(size_t)r * ld + c] * dir;
+            pivot(t, r, c, a > 0 ? t->lo[jr] : t->hi[jr]);
+        }
+    }
+}
+
+static void structural_x(const dict_t *t, double *x)
+{
+    for (int c = 0; c < t->n; ++c) if (t->nonbasic[c] < t->n) x[t->nonbasic[c]] = t->xN[c];
+    for (int r = 0; r < t->m; ++r) if (t->basic[r] < t->n) x[t->basic[r]] = t->xB[r];
+}
+
+static void matvecP(const dict_t *t, const double *x, double *y)
+{
+    const int n = t->n;
+    for (int i = 0; i < n; ++i) { const double *pi = t->P + (size_t)i * n; double s = 0; for (int j = 0; j < n; ++j) s += pi[j] * x[j]; y[i] = s; }
+}
+
+/* min 1/2 w'Hw + c'w over the unit simplex (p <= SD_PMAX), primal active set started from w (feasible) with index
+ * `enter` forced free.  H is p x p (ld SD_PMAX). */
+static void master_qp(int p, const double *H, const double *c, double *w, int enter)
+{
+    unsigned char F[SD_PMAX];
+    double K[(SD_PMAX + 1) * (SD_PMAX + 2)], sol[SD_PMAX + 1], wn[SD_PMAX];
+    for (int i = 0; i < p; ++i) F[i] = w[i] > 0 || i == enter;
+    for (int iter = 0; iter < 200; ++iter) {
+        int idx[SD_PMAX], nf = 0;
+        for (int i = 0; i < p; ++i) if (F[i]) idx[nf++] = i;
+        /* KKT: [H_FF 1; 1' 0] [w; nu] = [-c_F; 1] */
+        const int N1 = nf + 1;
+        double tr = 0; for (int a = 0; a < nf; ++a) tr += H[idx[a] * SD_PMAX + idx[a]];
+        const double ridge = 1e-14 * fmax(tr, 1e-300);
+        for (int a = 0; a < nf; ++a) {
+            for (int b = 0; b < nf; ++b) K[a * (N1 + 1) + b] = H[idx[a] * SD_PMAX + idx[b]] + (a == b ? ridge : 0.0);
+            K[a * (N1 + 1) + nf] = 1.0; K[a * (N1 + 1) + N1] = -c[idx[a]];
+        }
+        for (int b = 0; b < nf; ++b) K[nf * (N1 + 1) + b] = 1.0;
+        K[nf * (N1 + 1) + nf] = 0.0; K[nf * (N1 + 1) + N1] = 1.0;
+        for (int k = 0; k < N1; ++k) {      /* Gaussian elimination with partial pivoting */
+            int pv = k; double mx = fabs(K[k * (N1 + 1) + k]);
+            for (int a = k + 1; a < N1; ++a) if (fabs(K[a * (N1 + 1) + k]) > mx) { mx = fabs(K[a * (N1 + 1) + k]); pv = a; }
+            if (pv != k) for (int b = 0; b <= N1; ++b) { const double tmp = K[k * (N1 + 1) + b]; K[k * (N1 + 1) + b] = K[pv * (N1 + 1) + b]; K[pv * (N1 + 1) + b] = tmp; }
+            const double piv = K[k * (N1 + 1) + k];
+            if (fabs(piv) < 1e-300) continue;
+            for (int a = k + 1; a < N1; ++a) {
+                const double f = K[a * (N1 + 1) + k] / piv;
+                if (f != 0.0) for (int b = k; b <= N1; ++b) K[a * (N1 + 1) + b] -= f * K[k * (N1 + 1) + b];
+            }
+        }
+        for (int k = N1 - 1; k >= 0; --k) {
+            double sacc = K[k * (N1 + 1) + N1];
+            for (int b = k + 1; b < N1; ++b) sacc -= K[k * (N1 + 1) + b] * sol[b];
+            const double piv = K[k * (N1 + 1) + k];
+            sol[k] = fabs(piv) < 1e-300 ? 0.0 : sacc / piv;
+        }
+        for (int i = 0; i < p; ++i) wn[i] = 0.0;
+        for (int a = 0; a < nf; ++a) wn[idx[a]] = sol[a];
+        int blocking = -1; double alpha = 1.0;
+        for (int a = 0; a < nf; ++a) {
+            const int i = idx[a];
+            if (wn[i] < -1e-13 && w[i] - wn[i] > 0) { const double al = w[i] / (w[i] - wn[i]); if (al < alpha) { alpha = al; blocking = i; } }
+        }
+        if (blocking >= 0) {
+            for (int i = 0; i < p; ++i) w[i] += alpha * (wn[i] - w[i]);
+            w[blocking] = 0.0; F[blocking] = 0;
+            continue;
+        }
+        for (int i = 0; i < p; ++i) w[i] = wn[i] > 0 ? wn[i] : 0.0;
+        /* multipliers of the inactive vertices: g_i + nu >= 0 with nu = sol[nf] */
+        int add = -1; double worst = -1e-12;
+        for (int i = 0; i < p; ++i) {
+            if (F[i]) continue;
+            double g = c[i]; for (int j = 0; j < p; ++j) g += H[i * SD_PMAX + j] * w[j];
+            if (g + sol[nf] < worst) { worst = g + sol[nf]; add = i; }
+        }
+        if (add < 0) break;
+        F[add] = 1;
+    }
+    double sw = 0; for (int i = 0; i < p; ++i) sw += w[i];
+    if (sw > 0) for (int i = 0; i < p; ++i) w[i] /= sw;
+}
+
+/* Convex-QP relaxation of the current node by simplicial decomposition (von Hohenbalken 1977; fully corrective
+ * Frank-Wolfe).  On entry the dictionary is LP(q)-optimal for the node; on exit it is LP(q)-optimal again.
+ * Returns 0 and (lower bound *lb, relaxation value *fv, point v in t->vcur) -- or 1 if *lb already exceeds `cutoff`,
+ * or -1 on an iteration limit. */
+static int sd_relax(dict_t *t, double cutoff, double *lb_out, double *fv_out)
+{
+    const int n = t->n;
+    double *v = t->vcur, *Pv = t->Pv, *g = t->gcost;
+    double *Y = t->Y, *PY = t->PY, *H = t->Hm, *cm = t->cm, *w = t->wm;
+    int p = 1, rc = 0;
+    structural_x(t, Y);
+    matvecP(t, Y, PY);
+    { double s = 0, l = 0; for (int j = 0; j < n; ++j) { s += Y[j] * PY[j]; l += t->q[j] * Y[j]; } H[0] = s; cm[0] = l; }
+    w[0] = 1.0;
+    memcpy(v, Y, sizeof(double) * n); memcpy(Pv, PY, sizeof(double) * n);
+    double LB = -INFINITY, fv = 0;
+    for (int it = 0; it < 80; ++it) {
+        fv = 0; double gv = 0;
+        for (int j = 0; j < n; ++j) { g[j] = Pv[j] + t->q[j]; fv += v[j] * (0.5 * Pv[j] + t->q[j]); gv += g[j] * v[j]; }
+        reprice(t, g);
+        const int lp = primal_simplex(t);
+        if (lp != LP_OPTIMAL) { rc = -1; break; }
+        t->qp_iters++;
+        double *ynew = Y + (size_t)p * n;
+        if (p >= SD_PMAX) {   /* drop the lightest vertex */
+            int k = 0; for (int i = 1; i < p; ++i) if (w[i] < w[k]) k = i;
+            for (int i = k; i + 1 < p; ++i) {
+                memcpy(Y + (size_t)i * n, Y + (size_t)(i + 1) * n, sizeof(double) * n);
+                memcpy(PY + (size_t)i * n, PY + (size_t)(i + 1) * n, sizeof(double) * n);
+                w[i] = w[i + 1]; cm[i] = cm[i + 1];
+            }
+            for (int a = 0; a < p; ++a) for (int b = k; b + 1 < p; ++b) H[a * SD_PMAX + b] = H[a * SD_PMAX + b + 1];
+            for (int a = k; a + 1 < p; ++a) for (int b = 0; b < p; ++b) H[a * SD_PMAX + b] = H[(a + 1) * SD_PMAX + b];
+            p--; ynew = Y + (size_t)p * n;
+        }
+        structural_x(t, ynew);
+        double gy = 0; for (int j = 0; j < n; ++j) gy += g[j] * ynew[j];
+        const double lbt = fv + gy - gv;
+        if (lbt > LB) LB = lbt;
+        if (fv - LB <= 1e-10 * fmax(1.0, fabs(fv))) break;
+        if (LB > cutoff) { rc = 1; break; }
+        matvecP(t, ynew, PY + (size_t)p * n);
+        for (int i = 0; i <= p; ++i) {
+            double sacc = 0; const double *yi = Y + (size_t)i * n, *pyn = PY + (size_t)p * n;
+            for (int j = 0; j < n; ++j) sacc += yi[j] * pyn[j];
+            H[i * SD_PMAX + p] = H[p * SD_PMAX + i] = sacc;
+        }
+        { double l = 0; for (int j = 0; j < n; ++j) l += t->q[j] * ynew[j]; cm[p] = l; }
+        w[p] = 0.0;
+        p++;
+        master_qp(p, H, cm, w, p - 1);
+        /* drop zero-weight vertices, rebuild v and Pv */
+        int k2 = 0;
+        for (int i = 0; i < p; ++i) {
+            if (w[i] <= 0.0) continue;
+            if (k2 != i) {
+                memcpy(Y + (size_t)k2 * n, Y + (size_t)i * n, sizeof(double) * n);
+                memcpy(PY + (size_t)k2 * n, PY + (size_t)i * n, sizeof(double) * n);
+                w[k2] = w[i]; cm[k2] = cm[i];
+                for (int a = 0; a < p; ++a) H[a * SD_PMAX + k2] = H[a * SD_PMAX + i];
+                for (int b = 0; b < p; ++b) H[k2 * SD_PMAX + b] = H[i * SD_PMAX + b];
+            }
+            k2++;
+        }
+        p = k2;
+        for (int j = 0; j < n; ++j) { double a = 0, b = 0; for (int i = 0; i < p; ++i) { a += w[i] * Y[(size_t)i * n + j]; b += w[i] * PY[(size_t)i * n + j]; } v[j] = a; Pv[j] = b; }
+    }
+    reprice(t, t->q);
+    if (primal_simplex(t) != LP_OPTIMAL) rc = -1;
+    *lb_out = LB; *fv_out = fv;
+    return rc;
+}
+
 /* row-activity bound propagation with integer rounding (Savelsbergh 1994); returns 0 if infeasible */
 static int propagate_bounds(const double *G, const double *h, int m, int n, double *lb, double *ub,
                             const unsigned char *is_int)
@@ -617,7 +858,19 @@ static int gmi_round(dict_t *t, int max_cuts)
 
 static double gtol(const orc_opts *o, double v) { return fmax(o->gap_abs, o->gap_rel * fabs(v)); }
 
+int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double *G, const double *h, const double *lb_in,
+                   const double *ub_in, const unsigned char *is_bin, const orc_opts *o, double *x_out,
+                   double *obj_out, orc_stats *st);
+
 int orc_solve_milp(int n, int m, const double *q, const double *G, const double *h, const double *lb_in,
+                   const double *ub_in, const unsigned char *is_bin, const orc_opts *o, double *x_out,
+                   double *obj_out, orc_stats *st)
+{
+    return orc_solve_miqp(n, m, NULL, q, G, h, lb_in, ub_in, is_bin, o, x_out, obj_out, st);
+}
+
+/* min 1/2 x'Px + q'x  s.t. Gx <= h, lb <= x <= ub, x_i in {0,1} (i binary);  P symmetric PSD or NULL */
+int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double *G, const double *h, const double *lb_in,
                    const double *ub_in, const unsigned char *is_bin, const orc_opts *o, double *x_out,
                    double *obj_out, orc_stats *st)
 {
@@ -648,6 +901,15 @@ int orc_solve_milp(int n, int m, const double *q, const double *G, const double 
         t->hx[i] = h[i] * t->rs[i];
     }
     for (int j = 0; j < n; ++j) { t->q[j] = q[j] * t->cs[j]; t->lo[j] = lb[j] / t->cs[j]; t->hi[j] = ub[j] / t->cs[j]; }
+    double *Ps = NULL;
+    if (Pq) {
+        Ps = dalloc((size_t)n * n);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Ps[(size_t)i * n + j] = Pq[(size_t)i * n + j] * t->cs[i] * t->cs[j];
+        t->P = Ps;
+        t->Y = dalloc((size_t)(SD_PMAX + 1) * n); t->PY = dalloc((size_t)(SD_PMAX + 1) * n);
+        t->Hm = dalloc(SD_PMAX * SD_PMAX); t->cm = dalloc(SD_PMAX); t->wm = dalloc(SD_PMAX);
+        t->gcost = dalloc(n); t->vcur = dalloc(n); t->Pv = dalloc(n);
+    }
     for (int i = 0; i < t->mcap; ++i) { t->lo[n + i] = 0; t->hi[n + i] = INFINITY; }
     reset_dictionary(t);
     for (int c = 0; c < n; ++c) place(t, c);
@@ -696,6 +958,11 @@ int orc_solve_milp(int n, int m, const double *q, const double *G, const double 
         }
     }
     if (!root_ok) { status = ORC_NUMERICAL; goto done; }
+    if (t->P) {   /* root bound of the QP relaxation */
+        double lbq, fvq;
+        if (sd_relax(t, INFINITY, &lbq, &fvq) < 0) { status = ORC_NUMERICAL; goto done; }
+        st->root_bound = lbq;
+    } else
     st->root_bound = objective(t);
     memcpy(root_lo, t->lo, sizeof(double) * n); memcpy(root_hi, t->hi, sizeof(double) * n);
     {
@@ -722,11 +989,21 @@ int orc_solve_milp(int n, int m, const double *q, const double *G, const double 
                 if (getenv("ORC_DEBUG")) fprintf(stderr, "node %d depth %d lp=%d obj=%.12g cut=%.12g T=%.12g\n", nodes, depth, lp, objective(t), cut, T);
                 if (lp == LP_ITERLIMIT) limit = 1;
                 else if (lp == LP_OPTIMAL || lp == LP_CUTOFF) {
-                    const double obj = objective(t);
-                    if (lp == LP_CUTOFF || obj > cut) { if (obj <= inc_cut && obj < t_next) t_next = obj; }
+                    double obj = objective(t);       /* LP(q) value: a valid bound also when P is PSD */
+                    int pruned = (lp == LP_CUTOFF || obj > cut);
+                    if (!pruned && t->P) {
+                        double lbq, fvq;
+                        const int rc = sd_relax(t, cut, &lbq, &fvq);
+                        if (rc < 0) { limit = 1; pruned = 1; obj = INFINITY; }
+                        else { obj = lbq; pruned = (rc == 1 || obj > cut); }
+                    }
+                    if (pruned) { if (obj <= inc_cut && obj < t_next) t_next = obj; }
                     else {
+                        if (t->P) memcpy(xs, t->vcur, sizeof(double) * n);
+                        else {
                         for (int c = 0; c < n; ++c) if (t->nonbasic[c] < n) xs[t->nonbasic[c]] = t->xN[c];
                         for (int r = 0; r < t->m; ++r) if (t->basic[r] < n) xs[t->basic[r]] = t->xB[r];
+                        }
                         for (int k = 0; k < nb; ++k) {
                             const int j = bins[k];
                             if (fabs(xs[j] - rint(xs[j])) > ORC_INTTOL) { branch_j = j; branch_x = xs[j]; break; }
@@ -738,11 +1015,17 @@ int orc_solve_milp(int n, int m, const double *q, const double *G, const double 
                                 const int j = bins[k];
                                 if (t->lo[j] != t->hi[j]) { sv_j[ns] = j; sv_lo[ns] = t->lo[j]; sv_hi[ns] = t->hi[j]; ns++; const double v = rint(xs[j]); set_bounds(t, j, v, v); }
                             }
-                            if (dual_simplex(t, INFINITY) == LP_OPTIMAL) {
+                            int leaf_ok = dual_simplex(t, INFINITY) == LP_OPTIMAL;
+                            if (leaf_ok && t->P) { double lbq, fvq; leaf_ok = sd_relax(t, INFINITY, &lbq, &fvq) == 0; }
+                            if (leaf_ok) {
+                                if (t->P) for (int j = 0; j < n; ++j) xo[j] = t->vcur[j] * t->cs[j];
+                                else {
                                 for (int c = 0; c < n; ++c) if (t->nonbasic[c] < n) xo[t->nonbasic[c]] = t->xN[c] * t->cs[t->nonbasic[c]];
                                 for (int r = 0; r < t->m; ++r) if (t->basic[r] < n) xo[t->basic[r]] = t->xB[r] * t->cs[t->basic[r]];
+                                }
                                 for (int k = 0; k < nb; ++k) xo[bins[k]] = rint(xo[bins[k]]);
                                 double ob = 0; for (int j = 0; j < n; ++j) ob += q[j] * xo[j];
+                                if (Pq) for (int i = 0; i < n; ++i) { const double *pi = Pq + (size_t)i * n; double sq = 0; for (int j = 0; j < n; ++j) sq += pi[j] * xo[j]; ob += 0.5 * xo[i] * sq; }
                                 int feas = 1;
                                 for (int i = 0; i < m && feas; ++i) {
                                     double sa = -h[i]; const double *gi = G + (size_t)i * n;
@@ -794,6 +1077,7 @@ int orc_solve_milp(int n, int m, const double *q, const double *G, const double 
         st->lower_bound = status == ORC_OPTIMAL ? best : root_bound;
     }
 done:
+    if (Ps) { free(Ps); free(t->Y); free(t->PY); free(t->Hm); free(t->cm); free(t->wm); free(t->gcost); free(t->vcur); free(t->Pv); }
     st->pivots = (int)t->pivots; st->refactors = t->refactors; st->status = status;
     *obj_out = have ? best : INFINITY;
     free(lb); free(ub); free(t->D); free(t->Gx); free(t->hx); free(t->q); free(t->rs); free(t->cs); free(t->lo);

@@ -79,6 +79,28 @@ def solve_milp(q, G, h, lb, ub, is_bin, **kw):
                 root_bound=st.root_bound, lower_bound=st.lower_bound)
 
 
+def solve_miqp(P, q, G, h, lb, ub, is_bin, **kw):
+    """min 1/2 x'Px + q'x over the mixed-integer polytope (P symmetric PSD)"""
+    P = np.ascontiguousarray(P, np.float64)
+    q = np.ascontiguousarray(q, np.float64)
+    G = np.ascontiguousarray(G, np.float64)
+    h = np.ascontiguousarray(h, np.float64)
+    lb = np.ascontiguousarray(lb, np.float64)
+    ub = np.ascontiguousarray(ub, np.float64)
+    ib = np.ascontiguousarray(is_bin, np.uint8)
+    m, n = G.shape
+    x = np.zeros(n)
+    obj = C.c_double()
+    st = Stats()
+    o = make_opts(**kw)
+    lib().orc_solve_miqp.restype = C.c_int
+    s = lib().orc_solve_miqp(n, m, _p(P), _p(q), _p(G), _p(h), _p(lb), _p(ub), ib.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                             C.byref(o), _p(x), C.byref(obj), C.byref(st))
+    return dict(status=STATUS[s], obj=obj.value, x=x if np.isfinite(obj.value) else None, nodes=st.nodes,
+                pivots=st.pivots, cuts=st.cuts, refactors=st.refactors, root_lp=st.root_lp,
+                root_bound=st.root_bound, lower_bound=st.lower_bound)
+
+
 def enumerate_milp(q, G, h, lb, ub, is_bin):
     q = np.ascontiguousarray(q, np.float64)
     G = np.ascontiguousarray(G, np.float64)

@@ -152,8 +152,81 @@ def test_cost_assembly_kernel_matches_oracle_with_quadratic_atoms():
     for k in ("P", "q0", "Qx", "Qw"):
         ref = sf["cost"][k]
         assert np.abs(got[k][0] - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), k
-    with pytest.raises(gpu.MldGpuError, match="linear cost only"):
-        p.solve(ag["x0"], ag["omega"])
+    p.close(); m.close()
+
+
+def _miqp_oracle(agent, atoms, wl, s, fixed=None):
+    d = agent["dims"]
+    tm = tighten_np.tighten(agent["mats"], d, nu_l=d["nu_l"])
+    sf = cn.standard_form(tm, atoms, wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
+    h = cn.rhs(sf["evo"], agent["x0"][s], agent["omega"][s])
+    q = cn.lin_cost(sf["cost"], agent["x0"][s], agent["omega"][s])
+    r = cn.cost_const(sf["cost"]["const_terms"], agent["x0"][s], agent["omega"][s])
+    lb, ub, isb = sf["lb"].copy(), sf["ub"].copy(), sf["is_bin"].copy()
+    if fixed is not None:
+        bins = np.where(isb)[0]
+        lb[bins] = ub[bins] = fixed
+        isb = np.zeros_like(isb)
+    ref = orc.solve_miqp(sf["cost"]["P"], q, sf["G"], h, lb, ub, isb, max_nodes=20000, presolve=0)
+    return sf, q, h, r, ref
+
+
+@pytest.mark.parametrize("name,nb", [("cfg1", 4), ("cfg2", 5)])
+def test_miqp_solve_matches_oracle(name, nb):
+    """quadratic atoms (the MIQP variant Q_x = 1e-3 I plus a quadratic weight on y / u): convex-QP relaxation at
+    every node by simplicial decomposition, GPU vs the oracle's restatement of the same algorithm"""
+    wl = syn.make_workload(name, batch=nb, quadratic=True)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    atoms = dict(ag["atoms"])
+    atoms["Q_u"] = 0.05 * np.eye(d["nu"])
+    if d["ny"]:
+        atoms["q_Quadratic_y"] = 1e-4 if name == "cfg2" else 1e-2
+    m = gpu.GpuModel([ag["mats"]], d)
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], host.cost_from_atoms(atoms, d, wl["N_p"], wl["N_tilde"]), max_nodes=20000)
+    out = p.solve(ag["x0"], ag["omega"])
+    for s in range(nb):
+        sf, q, h, r, ref = _miqp_oracle(ag, atoms, wl, s)
+        assert gpu._lib.STATUS_NAMES[int(out["status"][s])] == ref["status"] == "optimal", (s, out["status"][s], ref["status"])
+        tot = ref["obj"] + r
+        assert abs(out["obj"][s] - tot) <= 1e-6 * max(1.0, abs(tot)), (s, out["obj"][s], tot)
+        v = out["v"][s]
+        bins = sf["is_bin"]
+        assert np.all((v[bins] == 0) | (v[bins] == 1))
+        sf0 = cn.standard_form(ag["mats"], atoms, wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
+        h0 = cn.rhs(sf0["evo"], ag["x0"][s], ag["omega"][s])
+        rown = np.maximum(1.0, np.abs(sf0["G"]).max(axis=1))
+        assert np.all((sf0["G"] @ v - h0) / rown <= 1e-6)
+        assert abs(0.5 * v @ sf["cost"]["P"] @ v + q @ v + r - out["obj"][s]) <= 1e-6 * max(1.0, abs(tot))
+    p.close(); m.close()
+
+
+def test_qp_relaxation_only_mode_binaries_fixed():
+    """BASELINE cfg2 as specified: QP relaxation kernel only, binaries fixed"""
+    wl = syn.make_workload("cfg2", batch=6, quadratic=True)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    atoms = dict(ag["atoms"])
+    atoms["q_Quadratic_z"] = 1e-3
+    m = gpu.GpuModel([ag["mats"]], d)
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], host.cost_from_atoms(atoms, d, wl["N_p"], wl["N_tilde"]))
+    rng = np.random.Generator(np.random.PCG64(9))
+    bins = np.where(p.is_bin)[0]
+    isdelta = (bins % m.nv) == d["nu"]
+    fixed = np.zeros((6, p.n_bin), dtype=np.uint8)
+    for s in range(6):
+        om = ag["omega"][s].reshape(wl["N_tilde"], -1)
+        u = (rng.random((wl["N_tilde"], d["nu"])) < 0.25).astype(np.uint8)
+        y = u @ ag["params"]["P_h_Nom"] + om[:, -1]
+        fixed[s, ~isdelta] = u.ravel()
+        fixed[s, isdelta] = (y >= 0).astype(np.uint8)
+    out = p.solve(ag["x0"], ag["omega"], fixed_bin=fixed)
+    for s in range(6):
+        sf, q, h, r, ref = _miqp_oracle(ag, atoms, wl, s, fixed=fixed[s])
+        assert gpu._lib.STATUS_NAMES[int(out["status"][s])] == ref["status"] == "optimal"
+        tot = ref["obj"] + r
+        assert out["nodes"][s] == 1
+        assert abs(out["obj"][s] - tot) <= 1e-6 * max(1.0, abs(tot)), (s, out["obj"][s], tot)
     p.close(); m.close()
 
 

@@ -111,3 +111,64 @@ def test_infeasible_and_node_limit_statuses():
     sf, q, h = _instance("cfg2", 0, tight=False)
     r = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], max_nodes=3, presolve=0)
     assert r["status"] in ("node_limit", "optimal")
+
+
+def _fw_gap(P, q, G, h, lb, ub, x):
+    """Frank-Wolfe optimality certificate of a convex QP, computed with HiGHS' LP: g.x - min_y g.y"""
+    from scipy.optimize import linprog
+    g = P @ x + q
+    r = linprog(g, A_ub=G, b_ub=h, bounds=np.c_[lb, ub], method="highs")
+    assert r.status == 0
+    return float(g @ x - r.fun)
+
+
+def test_convex_qp_relaxation_is_optimal_by_certificate():
+    rng = np.random.Generator(np.random.PCG64(3))
+    for t in range(8):
+        n, m, r = 12, 9, 5
+        G = rng.standard_normal((m, n))
+        xf = rng.random(n)
+        h = G @ xf + rng.random(m)
+        R = rng.standard_normal((r, n))
+        P, q = R.T @ R, rng.standard_normal(n)
+        lb, ub = np.zeros(n), np.full(n, 3.0)
+        res = orc.solve_miqp(P, q, G, h, lb, ub, np.zeros(n, bool))
+        assert res["status"] == "optimal"
+        x = res["x"]
+        assert np.all(G @ x <= h + 1e-8) and np.all(x >= -1e-9) and np.all(x <= 3 + 1e-9)
+        assert abs(0.5 * x @ P @ x + q @ x - res["obj"]) < 1e-9
+        assert _fw_gap(P, q, G, h, lb, ub, x) < 1e-7
+
+
+def test_small_miqp_matches_enumeration_of_the_binaries():
+    import itertools
+    rng = np.random.Generator(np.random.PCG64(4))
+    for t in range(6):
+        n, m, nb, r = 10, 7, 5, 4
+        G = rng.standard_normal((m, n))
+        xf = rng.random(n)
+        h = G @ xf + rng.random(m)
+        R = rng.standard_normal((r, n))
+        P, q = R.T @ R, rng.standard_normal(n)
+        lb = np.zeros(n)
+        ub = np.concatenate([np.ones(nb), np.full(n - nb, 3.0)])
+        isb = np.arange(n) < nb
+        res = orc.solve_miqp(P, q, G, h, lb, ub, isb)
+        best = np.inf
+        for bits in itertools.product([0, 1], repeat=nb):
+            l, u = lb.copy(), ub.copy()
+            l[:nb] = u[:nb] = bits
+            rr = orc.solve_miqp(P, q, G, h, l, u, np.zeros(n, bool))
+            if rr["status"] == "optimal":
+                assert _fw_gap(P, q, G, h, l, u, rr["x"]) < 1e-7
+                best = min(best, rr["obj"])
+        assert res["status"] == ("optimal" if np.isfinite(best) else "infeasible")
+        if np.isfinite(best):
+            assert abs(res["obj"] - best) <= 1e-7 * max(1, abs(best))
+
+
+def test_miqp_with_zero_hessian_equals_milp():
+    sf, q, h = _instance("cfg2", 1, tight=True)
+    a = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], presolve=0)
+    b = orc.solve_miqp(np.zeros((q.size, q.size)), q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], presolve=0)
+    assert a["status"] == b["status"] == "optimal" and abs(a["obj"] - b["obj"]) <= 1e-8 * max(1, abs(a["obj"]))
