@@ -16,3 +16,7 @@ print('solve_ms',st['solve_ms'],'pivots',st['pivots'],'nodes',st['nodes'],'inst'
 for n_,t in zip(names,ticks): print('%-18s %6.1f%%'%(n_, 100*t/ticks[:7].sum() if n_!='-' else 0))
 print('avg nnz(pivot row)', ticks[7]/st['pivots'], 'of', prob.n+1, '; avg rows touched', tel['rows_updated'].sum()/st['pivots'])
 print('sum-of-latency s', tot*1e-9, 'ticks total (100MHz?) s', ticks[:7].sum()/1e8, ' per pivot us (pivot_update)', ticks[0]/1e8/st['pivots']*1e6)
+out=prob.download(); lat=tel['latency_ns']*1e-9
+for s_,nm in ((0,'optimal'),(2,'node_limit')):
+    sel=out['status']==s_
+    print(nm, 'count', int(sel.sum()), 'share of WG-time %.1f%%'%(100*lat[sel].sum()/lat.sum()), 'mean ms %.1f'%(1e3*lat[sel].mean() if sel.any() else 0), 'mean pivots %.0f'%(out['pivots'][sel].mean() if sel.any() else 0))
