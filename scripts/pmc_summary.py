@@ -1,0 +1,52 @@
+"""Summarise rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs) into profiles/<tag>_pmc_solve.json.
+
+usage: python scripts/pmc_summary.py <fetch_dir> <write_dir> <out.json> [workload text]
+Counters are in KiB (MI355X_MICROARCH.md, HBM section).  FETCH_SIZE under-reports wide coalesced reads on gfx950
+by 2x; both the raw sum and the fetch-doubled upper bound are recorded.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def collect(d, counter):
+    out = {}
+    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != counter:
+                continue
+            k = row["Kernel_Name"].split("(")[0]
+            e = out.setdefault(k, {"launches": set(), "sum_kb": 0.0})
+            e["launches"].add(row["Dispatch_Id"])
+            e["sum_kb"] += float(row["Counter_Value"])
+    for k, e in out.items():
+        e["launches"] = len(e["launches"])
+        e["kb_per_launch"] = e["sum_kb"] / max(1, e["launches"])
+    return out
+
+
+def main():
+    fd, wd, dst = sys.argv[1:4]
+    workload = sys.argv[4] if len(sys.argv) > 4 else ""
+    fe, wr = collect(fd, "FETCH_SIZE"), collect(wd, "WRITE_SIZE")
+    f = fe.get("k_solve", {}).get("kb_per_launch", 0.0)
+    w = wr.get("k_solve", {}).get("kb_per_launch", 0.0)
+    doc = {
+        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu (two separate passes)",
+        "workload": workload,
+        "k_solve": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_raw": (f + w) * 1024.0,
+                    "hbm_bytes_fetch_x2": (2 * f + w) * 1024.0},
+        "hbm_bytes_per_launch": (f + w) * 1024.0,
+        "note": "per launch of k_solve; raw = (FETCH+WRITE)*1024 is what bench.py reports as `traffic`; "
+                "(2*FETCH+WRITE)*1024 is the upper bound if the gfx950 FETCH_SIZE 2x under-count for wide "
+                "coalesced reads applies to this kernel's 16 B/lane sector reads.",
+        "all": {"FETCH_SIZE": fe, "WRITE_SIZE": wr},
+    }
+    json.dump(doc, open(dst, "w"), indent=1)
+    print("k_solve FETCH %.3e B  WRITE %.3e B  raw %.3e B" % (f * 1024, w * 1024, (f + w) * 1024))
+
+
+if __name__ == "__main__":
+    main()
