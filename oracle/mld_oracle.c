@@ -969,28 +969,55 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
         /* Depth-first branch-and-bound with iterative deepening on the LP bound (Korf 1985): pass k
          * explores every node whose bound is <= min(T_k, incumbent - tol).  T starts at the root bound
          * (finds an optimal vertex of the optimal face quickly when the root bound is tight), grows
-         * geometrically while no incumbent exists and becomes +inf once one does. */
+         * geometrically while no incumbent exists and becomes +inf once one does.
+         *
+         * Primal side for the degenerate instances (phases): when the deepening passes have used a quarter of
+         * the node budget without an incumbent, (DIVE) one look-ahead dive -- the fractional binary closest to
+         * 1 goes up unless that raises the LP value, in which case the better child is taken -- produces an
+         * incumbent; (RINS) binaries on which the incumbent and the root relaxation agree are fixed and the
+         * remaining sub-problem is searched depth-first (Danna, Rothberg, Le Pape 2005), at most twice; (FINAL)
+         * the plain search continues with the incumbent as cutoff for the rest of the node budget. */
+        enum { PH_IDS = 0, PH_DIVE, PH_RINS, PH_FINAL };
         const double root_bound = st->root_bound;
         int nodes = 0, limit = 0, pass = 0, rescue = 0, node_budget = o->max_nodes;
+        int phase = PH_IDS, rins_rounds = 0, nfix = 0;
+        const int ids_cap = o->max_nodes / 4 > 16 ? o->max_nodes / 4 : 16;
+        const double dive_tol = 1e-2 * fmax(1.0, fabs(root_bound));
+        double *xroot = dalloc(nb + 1), *fx_lo = dalloc(nb + 1), *fx_hi = dalloc(nb + 1);
+        int *fx_j = (int *)calloc(nb + 1, sizeof(int));
         double T = root_bound + fmax(1e-7 * fmax(1.0, fabs(root_bound)), gtol(o, root_bound));
         status = ORC_NODE_LIMIT;
         for (;;) {
             int depth = 0;
             double t_next = INFINITY;   /* smallest bound among nodes pruned by T only */
-            int finished = 0;
+            int finished = 0, dive_end = 0;
+            const double best_at_start = best;
             pass++;
+            if (phase == PH_RINS) {   /* fix the binaries on which incumbent and root relaxation agree */
+                nfix = 0;
+                for (int k = 0; k < nb; ++k) {
+                    const int j = bins[k];
+                    if (root_lo[j] != root_hi[j] && fabs(xroot[k] - x_out[j]) <= ORC_INTTOL) {
+                        fx_j[nfix] = j; fx_lo[nfix] = root_lo[j]; fx_hi[nfix] = root_hi[j]; nfix++;
+                        root_lo[j] = root_hi[j] = x_out[j];
+                        set_bounds(t, j, x_out[j], x_out[j]);
+                    }
+                }
+            }
             for (;;) {
                 /* ---- evaluate the current node */
                 nodes++;
                 int branch_j = -1; double branch_x = 0;
                 const double inc_cut = have ? best - gtol(o, best) : INFINITY;
                 const double cut = fmin(T, inc_cut);
+                double node_obj = INFINITY;
                 lp = dual_simplex(t, cut + 1e-12);
-                if (getenv("ORC_DEBUG")) fprintf(stderr, "node %d depth %d lp=%d obj=%.12g cut=%.12g T=%.12g\n", nodes, depth, lp, objective(t), cut, T);
+                if (getenv("ORC_DEBUG")) fprintf(stderr, "node %d ph %d depth %d lp=%d obj=%.12g cut=%.12g T=%.12g\n", nodes, phase, depth, lp, objective(t), cut, T);
                 if (lp == LP_ITERLIMIT) limit = 1;
                 else if (lp == LP_OPTIMAL || lp == LP_CUTOFF) {
                     double obj = objective(t);       /* LP(q) value: a valid bound also when P is PSD */
                     int pruned = (lp == LP_CUTOFF || obj > cut);
+                    node_obj = obj;
                     if (!pruned && t->P) {
                         double lbq, fvq;
                         const int rc = sd_relax(t, cut, &lbq, &fvq);
@@ -1004,6 +1031,14 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                         for (int c = 0; c < n; ++c) if (t->nonbasic[c] < n) xs[t->nonbasic[c]] = t->xN[c];
                         for (int r = 0; r < t->m; ++r) if (t->basic[r] < n) xs[t->basic[r]] = t->xB[r];
                         }
+                        if (nodes == 1) for (int k = 0; k < nb; ++k) xroot[k] = xs[bins[k]];
+                        if (phase == PH_DIVE) {   /* fractional binary closest to 1 (first such index) */
+                            double bv = -1.0;
+                            for (int k = 0; k < nb; ++k) {
+                                const int j = bins[k];
+                                if (fabs(xs[j] - rint(xs[j])) > ORC_INTTOL && xs[j] > bv) { bv = xs[j]; branch_j = j; branch_x = xs[j]; }
+                            }
+                        } else
                         for (int k = 0; k < nb; ++k) {
                             const int j = bins[k];
                             if (fabs(xs[j] - rint(xs[j])) > ORC_INTTOL) { branch_j = j; branch_x = xs[j]; break; }
@@ -1039,24 +1074,67 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                     }
                 }
                 if (have && (rescue || best <= root_bound + gtol(o, best))) { finished = 1; }
-                if (nodes >= node_budget) limit = 1;
-                if (branch_j >= 0 && !limit && !finished) {
+                if (nodes >= ((phase == PH_IDS && !have && !rescue) ? ids_cap : node_budget)) limit = 1;
+                if (phase == PH_DIVE && !limit && !finished) {
+                    /* no backtracking: the dive ends at its first leaf, or when the node is infeasible */
+                    if (branch_j < 0) dive_end = 1;
+                    else {
+                        set_bounds(t, branch_j, 1.0, 1.0);
+                        nodes++;
+                        int la = dual_simplex(t, INFINITY);
+                        const double oa = la == LP_OPTIMAL ? objective(t) : INFINITY;
+                        double take = 1.0;
+                        if (la == LP_ITERLIMIT) limit = 1;
+                        else if (!(oa <= node_obj + dive_tol)) {
+                            set_bounds(t, branch_j, 0.0, 0.0);
+                            nodes++;
+                            const int lb2 = dual_simplex(t, INFINITY);
+                            const double ob2 = lb2 == LP_OPTIMAL ? objective(t) : INFINITY;
+                            if (lb2 == LP_ITERLIMIT) limit = 1;
+                            else if (ob2 <= oa) { take = 0.0; if (ob2 == INFINITY) dive_end = 1; }
+                            else set_bounds(t, branch_j, 1.0, 1.0);
+                        }
+                        (void)take;
+                        stk_j[depth] = branch_j; stk_first[depth] = take; stk_second[depth] = 1; depth++;
+                        if (!limit && !dive_end) continue; /* evaluate the chosen child */
+                    }
+                }
+                if (branch_j >= 0 && !limit && !finished && !dive_end) {
                     const double first = branch_x >= 0.5 ? 1.0 : 0.0;
                     stk_j[depth] = branch_j; stk_first[depth] = first; stk_second[depth] = 0; depth++;
                     set_bounds(t, branch_j, first, first);
                     continue; /* evaluate the child */
                 }
                 /* ---- backtrack */
-                if (limit || finished) { while (depth > 0) { depth--; set_bounds(t, stk_j[depth], root_lo[stk_j[depth]], root_hi[stk_j[depth]]); } break; }
+                if (limit || finished || dive_end) { while (depth > 0) { depth--; set_bounds(t, stk_j[depth], root_lo[stk_j[depth]], root_hi[stk_j[depth]]); } break; }
                 while (depth > 0 && stk_second[depth - 1]) { depth--; set_bounds(t, stk_j[depth], root_lo[stk_j[depth]], root_hi[stk_j[depth]]); }
                 if (depth == 0) break;
                 stk_second[depth - 1] = 1;
                 { const int j = stk_j[depth - 1]; const double v = 1.0 - stk_first[depth - 1]; set_bounds(t, j, v, v); }
             }
+            if (phase == PH_RINS) {   /* release the fixings */
+                for (int k = 0; k < nfix; ++k) { const int j = fx_j[k]; root_lo[j] = fx_lo[k]; root_hi[j] = fx_hi[k]; set_bounds(t, j, fx_lo[k], fx_hi[k]); }
+                rins_rounds++;
+            }
             if (finished) { if (!rescue) status = ORC_OPTIMAL; break; }
+            if (lp == LP_ITERLIMIT) break;
+            if (phase == PH_IDS && limit && !have && !rescue && nodes < o->max_nodes) {
+                phase = PH_DIVE; limit = 0; T = INFINITY; node_budget = o->max_nodes; continue;
+            }
+            if (phase == PH_DIVE) {
+                limit = nodes >= o->max_nodes;
+                if (have && !limit) { phase = PH_RINS; node_budget = nodes + (o->max_nodes * 3) / 8 < o->max_nodes ? nodes + (o->max_nodes * 3) / 8 : o->max_nodes; continue; }
+                if (!have && !limit) { phase = PH_FINAL; node_budget = o->max_nodes; continue; }
+            } else if (phase == PH_RINS) {
+                limit = nodes >= o->max_nodes;
+                if (!limit) {
+                    if (best < best_at_start && rins_rounds < 2) { node_budget = nodes + (o->max_nodes * 3) / 8 < o->max_nodes ? nodes + (o->max_nodes * 3) / 8 : o->max_nodes; continue; }
+                    phase = PH_FINAL; node_budget = o->max_nodes; continue;
+                }
+            }
             if (limit) {
                 /* node limit without an incumbent: one un-thresholded dive so that a feasible point is returned */
-                if (!have && !rescue && lp != LP_ITERLIMIT) { rescue = 1; limit = 0; T = INFINITY; node_budget = nodes + 3 * nb + 10; continue; }
+                if (!have && !rescue) { rescue = 1; limit = 0; T = INFINITY; phase = PH_FINAL; node_budget = nodes + 3 * nb + 10; continue; }
                 break;
             }
             /* the pass was exhaustive for its threshold */
@@ -1064,7 +1142,7 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
             if (!isfinite(t_next)) {
                 if (!have && !rescue) {   /* every node "infeasible": re-derive the dictionary from the original rows and dive once more */
                     refactor(t);
-                    rescue = 1; T = INFINITY; node_budget = nodes + 3 * nb + 10;
+                    rescue = 1; T = INFINITY; phase = PH_FINAL; node_budget = nodes + 3 * nb + 10;
                     continue;
                 }
                 status = have ? (rescue ? ORC_NODE_LIMIT : ORC_OPTIMAL) : ORC_INFEASIBLE;
@@ -1073,6 +1151,7 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
             if (have) T = INFINITY;
             else T = fmax(t_next + 1e-9 * fmax(1.0, fabs(t_next)), T + ldexp(2.5e-4, 2 * pass) * fmax(1.0, fabs(T)));
         }
+        free(xroot); free(fx_lo); free(fx_hi); free(fx_j);
         st->nodes = nodes;
         st->lower_bound = status == ORC_OPTIMAL ? best : root_bound;
     }
