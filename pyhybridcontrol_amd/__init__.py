@@ -4,9 +4,10 @@ Product path = libmldgpu.so (hand-written HIP for gfx950, C ABI in include/mldgp
 Python host layer.  There is no CPU fallback: compute entry points raise MldGpuError without a GPU.
 """
 from ._lib import MldGpuError, device_count, version  # noqa: F401
-from .mld_model import MldModel, MldInfo  # noqa: F401
+from .mld_model import MldModel, MldInfo, ParNotSet  # noqa: F401
 from .objective_atoms import ObjectiveAtoms  # noqa: F401
 from .controllers import (MpcController, MldEvoMatrices, ControllerBuildRequiredError,  # noqa: F401
                           ControllerSolverError)
 from .gpu import GpuModel, GpuProblem  # noqa: F401
 from .batch import BatchSolver, shard_range, gather_sharded  # noqa: F401
+from .aux_resolve import AuxResolver  # noqa: F401

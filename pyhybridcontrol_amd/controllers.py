@@ -378,13 +378,21 @@ class MpcController(object):
         return x, y
 
     def sim_step_k(self, k, x_k=None, u_k=None, omega_k=None, mld_numeric_k=None, solver=None, step_state=True):
-        """controller_base.py:229-253 with the MPC's own delta/z/mu (no auxiliary MIP)"""
+        """controller_base.py:229-253.  When the plant is the control model driven by the MPC's own (x, u, omega),
+        the solve's delta/z/mu are the auxiliaries and are reused; any override (another plant model, another x, u
+        or omega) resolves them from (x, u, omega) like the reference does at every step -- on the GPU
+        (MldModel._compute_aux -> aux_resolve.AuxResolver)."""
         var_k = self.variables_k
+        reuse = mld_numeric_k is None and x_k is None and u_k is None and omega_k is None
         omega_k = omega_k if omega_k is not None else var_k["omega"]
         x_k = x_k if x_k is not None else var_k["x"]
+        u_k = u_k if u_k is not None else var_k.get("u")
         sim_model = mld_numeric_k if mld_numeric_k is not None else self._model
-        lsim_k = sim_model.lsim_k(x_k=x_k, u_k=u_k if u_k is not None else var_k.get("u"), delta_k=var_k.get("delta"),
-                                  z_k=var_k.get("z"), mu_k=var_k.get("mu"), omega_k=omega_k)
+        if reuse:
+            lsim_k = sim_model.lsim_k(x_k=x_k, u_k=u_k, delta_k=var_k.get("delta"), z_k=var_k.get("z"),
+                                      mu_k=var_k.get("mu"), omega_k=omega_k)
+        else:
+            lsim_k = sim_model.lsim_k(x_k=x_k, u_k=u_k, omega_k=omega_k, solver=solver)
         if step_state:
             lsim_k.update({name + "_hat": val for name, val in var_k.items()})
             self._sim_log.set_sim_k(k=k, sim_k=lsim_k)

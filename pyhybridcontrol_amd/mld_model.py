@@ -13,6 +13,25 @@ import numpy as np
 
 from .objective_atoms import atleast_2d_col
 
+
+class _ParNotSetType(object):
+    """sentinel of the reference's utils.helper_funcs.ParNotSet: "argument not supplied" (None means zeros)"""
+    _inst = None
+
+    def __new__(cls):
+        if cls._inst is None:
+            cls._inst = object.__new__(cls)
+        return cls._inst
+
+    def __repr__(self):
+        return "ParNotSet"
+
+    def __bool__(self):
+        return False
+
+
+ParNotSet = _ParNotSetType()
+
 STATE_INPUT_MATS = ("A", "B1", "B2", "B3", "B4", "b5")
 OUTPUT_MATS = ("C", "D1", "D2", "D3", "D4", "d5")
 CONSTRAINT_MATS = ("E", "F1", "F2", "F3", "F4", "f5", "G", "Psi")
@@ -220,11 +239,28 @@ class MldModel(object):
         return info
 
     # -- one-step simulation with known auxiliaries (models/mld_model.py:647-699) ---------------------
-    def lsim_k(self, x_k=None, u_k=None, delta_k=None, z_k=None, mu_k=None, v_k=None, omega_k=None, cons_tol=1e-6):
-        """x(k+1), y(k) and constraint satisfaction for given (x,u,delta,z,mu,omega).  The reference resolves
-        unknown delta/z/mu with a cvxpy feasibility MIP (_compute_aux, :701-766); here they must be given
-        (the MPC solve returns them) -- resolving them on the GPU is SURVEY 8f item 1 (next)."""
+    def lsim_k(self, x_k=ParNotSet, u_k=ParNotSet, delta_k=ParNotSet, z_k=ParNotSet, mu_k=ParNotSet, v_k=ParNotSet,
+               omega_k=ParNotSet, solver=None, cons_tol=1e-6):
+        """x(k+1), y(k) and hard-constraint satisfaction for given (x, u, omega) (models/mld_model.py:647-699).
+        ``None`` means zeros; auxiliaries left at ``ParNotSet`` are resolved like the reference's ``_compute_aux``
+        (:701-766) -- here as a horizon-1 instance of the GPU path (aux_resolve.AuxResolver; no CPU fallback)."""
         info = self._mld_info
+        if omega_k is ParNotSet and info.nomega:
+            raise ValueError("variable omega_k cannot be set to ParNotSet")
+        if v_k is not ParNotSet and not all(a is ParNotSet for a in (u_k, delta_k, z_k, mu_k)):
+            raise ValueError("Either supply concatenated input in 'v_k' or supply individual inputs "
+                             "'u_k', 'delta_k', 'z_k' and 'mu_k', but not both.")
+        if v_k is ParNotSet:
+            if u_k is ParNotSet and info.nu:
+                raise ValueError("variable u_k cannot be set to ParNotSet")
+            unknown = tuple(n for n, a in (("delta", delta_k), ("z", z_k), ("mu", mu_k))
+                            if a is ParNotSet and info["n" + n] > 0)
+            if unknown:
+                delta_k, z_k, mu_k = self._compute_aux(x_k=x_k, u_k=u_k, delta_k=delta_k, z_k=z_k, mu_k=mu_k,
+                                                       omega_k=omega_k, unknown=unknown)
+        x_k, u_k, delta_k, z_k, mu_k, omega_k = [None if a is ParNotSet else a for a in (x_k, u_k, delta_k, z_k, mu_k, omega_k)]
+        if v_k is ParNotSet:
+            v_k = None
 
         def col(v, dim):
             if v is None or dim == 0:
@@ -245,3 +281,27 @@ class MldModel(object):
                 + m["Psi"] @ (mu_k * 0) - f5 <= cons_tol)          # hard-constraint satisfaction, as :692-694
         return dict(x_k1=x_k1, x=x_k, u=u_k, delta=delta_k, z=z_k, mu=mu_k, v=np.vstack((u_k, delta_k, z_k, mu_k)),
                     y=y_k, omega=omega_k, cons=cons)
+
+    def _compute_aux(self, x_k=ParNotSet, u_k=ParNotSet, delta_k=ParNotSet, z_k=ParNotSet, mu_k=ParNotSet,
+                     omega_k=ParNotSet, unknown=None, solver=None):
+        """the (delta, z, mu) completing (x, u, omega): feasibility MIP of models/mld_model.py:701-766 on the GPU.
+        Infeasible -> NaN columns, as the reference returns when the solver yields no value (:757-763)."""
+        from .aux_resolve import AuxResolver
+        info = self._mld_info
+        if unknown is None:
+            unknown = tuple(n for n, a in (("delta", delta_k), ("z", z_k), ("mu", mu_k)) if a is ParNotSet and info["n" + n] > 0)
+        key = tuple(unknown)
+        cache = self.__dict__.setdefault("_aux_resolvers", {})
+        if key not in cache:
+            cache[key] = AuxResolver(self.as_mats(), info.as_gpu_dims(), unknown=key)
+        res = cache[key]
+
+        def row(a, dim):
+            if a is ParNotSet or a is None or dim == 0:
+                return None if a is ParNotSet else np.zeros((1, dim))
+            return atleast_2d_col(a).reshape(1, dim)
+        out = res.resolve(np.zeros((1, info.nx)) if row(x_k, info.nx) is None else row(x_k, info.nx),
+                          np.zeros((1, info.nu)) if row(u_k, info.nu) is None else row(u_k, info.nu),
+                          np.zeros((1, info.nomega)) if row(omega_k, info.nomega) is None else row(omega_k, info.nomega),
+                          delta=row(delta_k, info.ndelta), z=row(z_k, info.nz), mu=row(mu_k, info.nmu))
+        return tuple(out[n].reshape(-1, 1) for n in ("delta", "z", "mu"))

@@ -304,3 +304,28 @@ def test_full_size_batch_properties_cfg3():
     assert np.array_equal(np.concatenate([a["obj"], b["obj"]]), out["obj"])
     assert np.array_equal(np.concatenate([a["v"], b["v"]]), V)
     p.close(); m.close()
+
+
+def test_maximum_size_cfg5_condense_and_solve_certificates():
+    """BASELINE cfg5 shape (n_h=15, N_p=48: n=2303, 784 binaries, m=1764; 36 MB dictionary per slot, hot basis
+    state only partly LDS-resident): condensing vs the numpy oracle and, for a few instances under a small node
+    limit, the size-independent certificates (integer feasible for the original rows, reported cost, bound)."""
+    wl = syn.make_workload("cfg5", batch=6)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    m = gpu.GpuModel([ag["mats"]], d)
+    evo = m.condense(wl["N_tilde"])
+    ref = cn.condense(ag["mats"], wl["N_tilde"])
+    for k in ("Phi_x", "Gamma_v", "Gamma_omega", "Gamma_5", "H_x", "H_v", "H_omega", "H_5"):
+        err = np.abs(evo[k][0] - ref[k]).max() / max(1.0, np.abs(ref[k]).max())
+        assert err < 1e-11, (k, err)
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"]),
+                       gap_rel=1e-2, max_nodes=40, max_pivots=6000)
+    out = p.solve(ag["x0"], ag["omega"])
+    assert set(np.unique(out["status"])) <= {0, 2}, out["status"]
+    fin = np.isfinite(out["obj"])
+    assert fin.sum() >= 4
+    for s in np.where(fin)[0]:
+        check_solution(ag, wl, s, out["v"][s], out["obj"][s])
+        assert out["lower_bound"][s] <= out["obj"][s] + 1e-6
+    p.close(); m.close()
