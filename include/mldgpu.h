@@ -143,6 +143,16 @@ int mld_solve_batch(mld_problem_t *, int batch, const int32_t *model_idx, const 
 /* The same in three steps so that a benchmark can time the device work with inputs resident in HBM. */
 int mld_upload_batch(mld_problem_t *, int batch, const int32_t *model_idx, const double *x0, const double *omega,
                      const uint8_t *fixed_bin);
+
+/* Extra constraint blocks of the uploaded batch.  Replaces `set_constraints(other_constraints=[gen_evo_constraints(
+ * omega_scenarios_k=..., N_tilde=...), ...])` (controllers/controller_base.py:457-475 with :411-456; callers
+ * examples/.../micro_grid_control_simulation.py:200-227: scenario-based and min-max controllers).  Every block
+ * has the standard block's left-hand side H_v (a row prefix when its N_tilde is reduced), so the stacked system is the
+ * standard one with the row-wise minimum right-hand side.  omega_cols (batch, n_cols, N_tilde*nomega): the
+ * disturbance columns of all blocks (scenario columns, min / max profiles; pad reduced-horizon columns with zeros);
+ * col_rows (n_cols) = number of leading constraint rows column c applies to (NULL = all rows).  Valid until the
+ * next mld_upload_batch; n_cols = 0 clears. */
+int mld_upload_constraint_blocks(mld_problem_t *, int n_cols, const double *omega_cols, const int32_t *col_rows);
 int mld_solve_resident(mld_problem_t *, mld_stats *stats_out);
 int mld_download_results(mld_problem_t *, double *v_out, double *obj_out, int32_t *status_out,
                          double *lower_bound_out, int32_t *nodes_out, int32_t *pivots_out);

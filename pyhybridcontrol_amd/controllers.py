@@ -19,6 +19,7 @@ import numpy as np
 from . import gpu
 from ._lib import MldGpuError, STATUS_NAMES
 from .mld_model import MldModel
+from .mld_model import ParNotSet
 from .objective_atoms import ObjectiveAtoms, atleast_2d_col
 
 
@@ -110,8 +111,11 @@ class MldEvoMatrices(dict):
 class EvoConstraint(object):
     """numeric stand-in for the cvxpy constraint  LHS @ v <= RHS  returned by gen_evo_constraints"""
 
-    def __init__(self, H_v, rhs):
+    def __init__(self, H_v, rhs, omega_cols=None, rows=None, x_is_parameter=True):
         self.H_v, self.rhs = H_v, rhs
+        # what the block was generated from: disturbance columns (N_tilde*nomega, S) padded to the full horizon, the
+        # number of constraint rows it spans, and whether x_k was the controller's parameter (updated at solve time)
+        self.omega_cols, self.rows, self.x_is_parameter = omega_cols, rows, x_is_parameter
 
 
 class MldSimLog(dict):
@@ -238,6 +242,7 @@ class MpcController(object):
     def gen_evo_constraints(self, x_k=None, omega_tilde_k=None, omega_scenarios_k=None, N_tilde=None):
         """H_v v <= H_x x_k + H_omega omega + H_5 ; with omega_scenarios_k the row-min over scenario
         columns of H_omega @ Omega (controller_base.py:411-456).  RHS computed by kernel K3."""
+        x_is_parameter = x_k is None
         x_k = self._x_k if x_k is None else self._check_shape("x_k", x_k, (self.mld_info_k.nx, 1))
         N_t = self._N_tilde if N_tilde is None else N_tilde
         if not N_t <= self._N_tilde:
@@ -251,18 +256,32 @@ class MpcController(object):
             if Om.shape[0] == N_t * info.nomega and N_t < self._N_tilde:
                 Om = np.vstack([Om, np.zeros(((self._N_tilde - N_t) * info.nomega, Om.shape[1]))])
             h = prob.rhs(x_k.T, Om.T[np.newaxis], scenarios=Om.shape[1])[0]
+            cols = Om
         else:
             om = self._omega_tilde_k if omega_tilde_k is None else atleast_2d_col(omega_tilde_k)
             if om.shape[0] == N_t * info.nomega and N_t < self._N_tilde:
                 om = np.vstack([om, np.zeros(((self._N_tilde - N_t) * info.nomega, 1))])
             h = prob.rhs(x_k.T, om.T)[0]
+            cols = om
         rows = N_t * info.n_constraints
         H_v = self.mld_evo_matrices.constraint["H_v_N_tilde"][:rows]
-        return EvoConstraint(H_v, h[:rows].reshape(-1, 1))
+        return EvoConstraint(H_v, h[:rows].reshape(-1, 1), omega_cols=np.array(cols, dtype=np.float64), rows=rows,
+                             x_is_parameter=x_is_parameter)
 
-    def set_constraints(self, std_evo_constaints=None, other_constraints=None, disable_soft_constraints=False):
-        if other_constraints:
-            raise NotImplementedError("extra constraint blocks (scenario / min-max variants) are SURVEY 8f item 2 (next)")
+    def set_constraints(self, std_evo_constaints=ParNotSet, other_constraints=ParNotSet, disable_soft_constraints=False):
+        """controller_base.py:457-475.  `other_constraints`: blocks from gen_evo_constraints (scenario columns, min / max
+        disturbance profiles, reduced N_tilde); they share the standard block's left-hand side, so on the GPU they
+        become extra right-hand-side columns reduced by a row-wise minimum (mld_upload_constraint_blocks)."""
+        if std_evo_constaints is not ParNotSet and std_evo_constaints is not None:
+            raise NotImplementedError("custom standard evolution constraints")
+        if other_constraints is not ParNotSet:
+            blocks = list(other_constraints or [])
+            for b in blocks:
+                if not isinstance(b, EvoConstraint) or b.omega_cols is None:
+                    raise TypeError("other_constraints must come from gen_evo_constraints()")
+                if not b.x_is_parameter:
+                    raise NotImplementedError("constraint blocks generated with an explicit x_k")
+            self._other_constraints = blocks
         if disable_soft_constraints and self.mld_info_k.nmu:
             raise NotImplementedError("disable_soft_constraints (mu == 0) is not on the GPU path yet")
         self._build_required = True
@@ -327,7 +346,11 @@ class MpcController(object):
                 self._problem = None
                 self.build(sense="min" if self._sense > 0 else "max")
             try:
-                out = self._problem.solve(self._x_k.T, self._omega_tilde_k.T)
+                cols = rows = None
+                if getattr(self, "_other_constraints", None):
+                    cols = np.hstack([b.omega_cols for b in self._other_constraints]).T[np.newaxis]
+                    rows = np.concatenate([np.full(b.omega_cols.shape[1], b.rows) for b in self._other_constraints])
+                out = self._problem.solve(self._x_k.T, self._omega_tilde_k.T, omega_cols=cols, col_rows=rows)
             except MldGpuError as e:
                 self._solve_time_solver = np.nan
                 raise ControllerSolverError(str(e)) from e

@@ -188,6 +188,21 @@ class GpuProblem(object):
         self.batch = batch
         return batch
 
+    def upload_constraint_blocks(self, omega_cols, col_rows=None):
+        """extra constraint blocks for the uploaded batch (mld_upload_constraint_blocks): omega_cols (batch, n_cols,
+        N_tilde*nomega), col_rows (n_cols) leading rows each column constrains (None = all); None / empty clears"""
+        if omega_cols is None or np.size(omega_cols) == 0:
+            check(_lib.load().mld_upload_constraint_blocks(self._h, 0, None, None))
+            return 0
+        cols = _lib.as_f64(omega_cols).reshape(self.batch, -1, self.nW)
+        n_cols = cols.shape[1]
+        cr = None
+        if col_rows is not None:
+            cr = np.ascontiguousarray(col_rows, dtype=np.int32).reshape(n_cols)
+        check(_lib.load().mld_upload_constraint_blocks(self._h, n_cols, _lib.dptr(cols),
+                                                       cr.ctypes.data_as(C.POINTER(C.c_int32)) if cr is not None else None))
+        return n_cols
+
     def solve_resident(self):
         st = _lib.Stats()
         check(_lib.load().mld_solve_resident(self._h, C.byref(st)))
@@ -211,8 +226,10 @@ class GpuProblem(object):
         check(_lib.load().mld_download_telemetry(self._h, ip(lat), ip(rows), C.byref(rb)))
         return dict(latency_ns=lat, rows_updated=rows, row_bytes=int(rb.value))
 
-    def solve(self, x0, omega, model_idx=None, fixed_bin=None):
+    def solve(self, x0, omega, model_idx=None, fixed_bin=None, omega_cols=None, col_rows=None):
         self.upload(x0, omega, model_idx, fixed_bin)
+        if omega_cols is not None:
+            self.upload_constraint_blocks(omega_cols, col_rows)
         stats = self.solve_resident()
         out = self.download()
         out["stats"] = stats

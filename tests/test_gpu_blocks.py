@@ -1,0 +1,135 @@
+"""GPU parity for extra constraint blocks: set_constraints(other_constraints=[gen_evo_constraints(...)])
+(controllers/controller_base.py:411-475; scenario-based and min-max controllers of the reference's example,
+micro_grid_control_simulation.py:200-227).  All blocks share H_v, so the stacked system is the standard one with
+the row-wise minimum right-hand side -- checked against the oracle solving the explicitly stacked problem."""
+import numpy as np
+import pytest
+
+import condense_np as cn
+import orc
+import tighten_np
+import pyhybridcontrol_amd as phc
+from pyhybridcontrol_amd import gpu, host, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _draw_profiles(ag, wl, rng, S):
+    """S disturbance profiles: the hot-water draws (soft temperature rows) scaled, the net load kept -- the tie rows
+    encode z = max(0, y) exactly, so a block with another load would make the stacked system infeasible"""
+    n_h = ag["dims"]["nx"]
+    base = ag["omega"][0].reshape(wl["N_tilde"], n_h + 1)
+    out = []
+    for _ in range(S):
+        w = base.copy()
+        w[:, :n_h] *= rng.uniform(0.3, 3.0, size=(1, n_h))
+        out.append(w.ravel())
+    return np.stack(out)
+
+
+def test_stacked_blocks_equal_row_min_rhs_vs_oracle():
+    from scipy.optimize import linprog
+    wl = syn.make_workload("cfg2", batch=4)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    N_t, nc = wl["N_tilde"], d["nc"]
+    rng = np.random.default_rng(5)
+    m = gpu.GpuModel([ag["mats"]], d)
+    p = gpu.GpuProblem(m, wl["N_p"], N_t, host.cost_from_atoms(ag["atoms"], d, wl["N_p"], N_t), max_nodes=20000)
+    B, S = 4, 5
+    cols = np.stack([_draw_profiles(dict(ag, omega=ag["omega"][b:b + 1]), wl, rng, S) for b in range(B)])   # (B, S, nW)
+    col_rows = np.array([N_t * nc, N_t * nc, 8 * nc, 8 * nc, 3 * nc], dtype=np.int32)   # two full blocks, reduced horizons
+    plain = p.solve(ag["x0"][:B], ag["omega"][:B])
+    tm = tighten_np.tighten(ag["mats"], d, nu_l=d["nu_l"])
+    sf = cn.standard_form(tm, ag["atoms"], wl["N_p"], N_t, nu_l=d["nu_l"])
+    sf0 = cn.standard_form(ag["mats"], ag["atoms"], wl["N_p"], N_t, nu_l=d["nu_l"])
+    bins = sf0["is_bin"]
+    rown = np.maximum(1.0, np.abs(sf0["G"]).max(axis=1))
+
+    # (a) exact: binaries fixed at the unconstrained optimum -> an LP.  GPU (tightened rows, row-min right-hand side)
+    #     vs HiGHS on the explicitly stacked ORIGINAL rows  [G; G[:r1]; ...] v <= [h; h_1[:r1]; ...]  the reference builds
+    fixed = np.rint(plain["v"][:, bins]).astype(np.uint8)
+    lp = p.solve(ag["x0"][:B], ag["omega"][:B], fixed_bin=fixed, omega_cols=cols, col_rows=col_rows)
+    for s in range(B):
+        Gs, hs = [sf0["G"]], [cn.rhs(sf0["evo"], ag["x0"][s], ag["omega"][s])]
+        for c in range(S):
+            r = int(col_rows[c])
+            Gs.append(sf0["G"][:r]); hs.append(cn.rhs(sf0["evo"], ag["x0"][s], cols[s, c])[:r])
+        lb, ub = sf0["lb"].copy(), sf0["ub"].copy()
+        lb[bins] = ub[bins] = fixed[s]
+        q = cn.lin_cost(sf0["cost"], ag["x0"][s], ag["omega"][s])
+        r0 = cn.cost_const(sf0["cost"]["const_terms"], ag["x0"][s], ag["omega"][s])
+        ref = linprog(q, A_ub=np.vstack(Gs), b_ub=np.concatenate(hs), bounds=np.c_[lb, ub], method="highs")
+        assert ref.status == 0 and lp["status"][s] == 0
+        assert abs(lp["obj"][s] - (ref.fun + r0)) <= 1e-6 * max(1.0, abs(ref.fun + r0)), (s, lp["obj"][s], ref.fun + r0)
+        assert lp["obj"][s] >= plain["obj"][s] - 1e-9            # more constraints never help
+
+    # (b) the MILP with blocks vs the oracle on the same (tightened, row-min) problem
+    out = p.solve(ag["x0"][:B], ag["omega"][:B], omega_cols=cols, col_rows=col_rows)
+    n_cmp, bound_any = 0, False
+    for s in range(B):
+        h = cn.rhs(sf["evo"], ag["x0"][s], ag["omega"][s]).copy()
+        for c in range(S):
+            r = int(col_rows[c])
+            h[:r] = np.minimum(h[:r], cn.rhs(sf["evo"], ag["x0"][s], cols[s, c])[:r])
+        q = cn.lin_cost(sf["cost"], ag["x0"][s], ag["omega"][s])
+        r0 = cn.cost_const(sf["cost"]["const_terms"], ag["x0"][s], ag["omega"][s])
+        ref = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], max_nodes=20000, presolve=0)
+        if ref["status"] == "optimal" and out["status"][s] == 0:
+            n_cmp += 1
+            assert abs(out["obj"][s] - (ref["obj"] + r0)) <= 1e-6 * max(1.0, abs(ref["obj"] + r0)), (s, out["obj"][s], ref["obj"] + r0)
+        if np.isfinite(out["obj"][s]):
+            bound_any |= out["obj"][s] > plain["obj"][s] + 1e-6
+            v = out["v"][s]                                      # every block holds in the ORIGINAL rows
+            assert np.all((v[bins] == 0) | (v[bins] == 1))
+            assert np.all((sf0["G"] @ v - cn.rhs(sf0["evo"], ag["x0"][s], ag["omega"][s])) / rown <= 1e-6)
+            for c in range(S):
+                r = int(col_rows[c])
+                assert np.all(((sf0["G"] @ v - cn.rhs(sf0["evo"], ag["x0"][s], cols[s, c])) / rown)[:r] <= 1e-6)
+    assert n_cmp >= 2 and bound_any
+    again = p.solve(ag["x0"][:B], ag["omega"][:B])                  # blocks belong to one upload only
+    assert np.array_equal(again["obj"], plain["obj"])
+    p.close(); m.close()
+
+
+def test_controller_scenario_and_minmax_blocks():
+    """the reference's mpc_sb_reduced / mpc_minmax call sequence on the SURVEY 8c DEWH instance"""
+    model = phc.MldModel(A=[[0.9970371127900564]], B1=[[4.298192277481107]], B4=[[-179.73320827515]],
+                         b5=[[0.07407218024859108]], E=[[1], [-1]], F1=[[0], [0]], Psi=[[-1, 0], [0, -1]],
+                         f5=[[65.0], [-50.0]], nu_l=1, ts=900)
+    ctrl = phc.MpcController(model, N_p=4)
+    price = np.array([1, 3, 3, 1, 1.0])
+    ctrl.set_std_obj_atoms(q_u=(price * 0.75).reshape(-1, 1), q_mu=[90.0, 90.0])
+    ctrl.build()
+    om = np.array([.004, .012, 0, .009, .002])
+    base = ctrl.solve(0, x_k=[50.3], omega_tilde_k=om)
+    assert abs(base - 1.5) < 1e-9
+    # min-max: the horizon must hold for a low-draw and a high-draw profile as well
+    lo, hi = om * 0.2, om * 2.5
+    min_cons = ctrl.gen_evo_constraints(N_tilde=5, omega_tilde_k=lo)
+    max_cons = ctrl.gen_evo_constraints(N_tilde=5, omega_tilde_k=hi)
+    ctrl.set_constraints(other_constraints=[min_cons, max_cons])
+    with pytest.raises(phc.ControllerBuildRequiredError):
+        ctrl.solve(0)
+    ctrl.build()
+    mm = ctrl.solve(0, x_k=[50.3], omega_tilde_k=om)
+    assert mm >= base - 1e-9 and mm > base + 1e-6              # heavier draws need more heating (or slack)
+    v = ctrl.v_N_tilde
+    for cons in (ctrl.gen_evo_constraints(), min_cons, max_cons):
+        assert np.all(cons.H_v @ v <= cons.rhs + 1e-7)
+    # scenario-based with a reduced horizon: three scenario columns over the first 3 steps only
+    Om = np.stack([om[:3] * f for f in (0.5, 1.0, 3.0)], axis=1)
+    sb = ctrl.gen_evo_constraints(N_tilde=3, omega_scenarios_k=Om)
+    assert sb.H_v.shape[0] == 3 * 2 and sb.rhs.shape == (6, 1)
+    ctrl.set_constraints(other_constraints=[sb])
+    ctrl.build()
+    sbv = ctrl.solve(0, x_k=[50.3], omega_tilde_k=om)
+    v = ctrl.v_N_tilde
+    assert np.all(sb.H_v @ v <= sb.rhs + 1e-7) and sbv >= base - 1e-9
+    ctrl.set_constraints(other_constraints=None)                # clears the blocks
+    ctrl.build()
+    assert abs(ctrl.solve(0, x_k=[50.3], omega_tilde_k=om) - 1.5) < 1e-9
+    with pytest.raises(TypeError):
+        ctrl.set_constraints(other_constraints=[object()])
+    with pytest.raises(NotImplementedError):
+        ctrl.set_constraints(other_constraints=[ctrl.gen_evo_constraints(x_k=[51.0])])
