@@ -12,7 +12,7 @@ out=(C.c_int64*8)(); _lib.load().mld_debug_profile(prob._h, out)
 tel=prob.telemetry(); tot=tel['latency_ns'].sum()
 names=['pivot_update','simplex_select','cuts','leaf','set_bounds','residual/refactor','setup','-']
 ticks=np.array(list(out),dtype=float); 
-print('solve_ms',st['solve_ms'],'pivots',st['pivots'],'nodes',st['nodes'],'inst',x0.shape[0])
+print('solve_ms',st['solve_ms'],'pivots',st['pivots'],'nodes',st['nodes'],'inst',x0.shape[0],'refactors',st['refactors'],'cuts',st['cuts'])
 for n_,t in zip(names,ticks): print('%-18s %6.1f%%'%(n_, 100*t/ticks[:7].sum() if n_!='-' else 0))
 print('avg nnz(pivot row)', ticks[7]/st['pivots'], 'of', prob.n+1, '; avg rows touched', tel['rows_updated'].sum()/st['pivots'])
 print('sum-of-latency s', tot*1e-9, 'ticks total (100MHz?) s', ticks[:7].sum()/1e8, ' per pivot us (pivot_update)', ticks[0]/1e8/st['pivots']*1e6)
