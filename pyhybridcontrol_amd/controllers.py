@@ -126,11 +126,47 @@ class MldSimLog(dict):
         self.update_sim_k(k, sim_k, **kwargs)
 
     def update_sim_k(self, k, sim_k=None, **kwargs):
+        if sim_k is not None and not isinstance(sim_k, dict):
+            raise TypeError("sim_k must be subtype of dict or None, not: %r" % type(sim_k).__name__)
         entry = dict(self.get(k, {}))
         for name, val in dict(sim_k or {}, **kwargs).items():
             if val is not None:
-                entry[name] = atleast_2d_col(val)
-        self[k] = entry
+                val = atleast_2d_col(val)
+                if name in entry and entry[name].shape != val.shape:
+                    raise ValueError("shape of var_k must match previous inserts")
+                entry[name] = val
+        dict.__setitem__(self, k, entry)
+
+    def __setitem__(self, k, sim_k):
+        self.set_sim_k(k=k, sim_k=sim_k)
+
+    def get_concat_log(self, add_column_levels=None):
+        """one pandas DataFrame over all logged steps: index k, columns (var_names, var_index); steps that never logged
+        a variable show NaN there (controller_base.py:116-146)"""
+        import pandas as pd
+        index = sorted(self)
+        shapes = {}
+        for k in index:
+            for name, val in self[k].items():
+                shapes.setdefault(name, val.shape[0])
+        frames = {}
+        for name, dim in shapes.items():
+            if dim == 0:
+                continue
+            numeric = all(np.issubdtype(self[k][name].dtype, np.number) or self[k][name].dtype == bool
+                          for k in index if name in self[k])
+            block = np.full((len(index), dim), np.nan if numeric else None, dtype=float if numeric else object)
+            for r, k in enumerate(index):
+                if name in self[k]:
+                    block[r] = self[k][name][:, 0]
+            frames[name] = pd.DataFrame(block)
+        df = pd.concat(frames, keys=list(frames), axis=1)
+        df.columns.names = ["var_names", "var_index"]
+        df.index = index
+        df.index.name = "k"
+        if add_column_levels:
+            df = pd.concat([df], keys=[add_column_levels], axis=1)
+        return df
 
 
 class MpcController(object):

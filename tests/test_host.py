@@ -109,3 +109,66 @@ def test_no_cpu_fallback_without_a_device():
         ctrl.solve(0, x_k=[1.0])
     with pytest.raises(phc.MldGpuError, match="no HIP device"):
         ctrl.build()
+
+
+def test_fold_known_preserves_the_constraint_statement():
+    """aux_resolve.fold_known: with u (and any known auxiliaries) moved into the disturbance channel, the folded
+    model's rows evaluate to the original model's rows (models/mld_model.py:735-744) for arbitrary values"""
+    from pyhybridcontrol_amd.aux_resolve import fold_known
+    from pyhybridcontrol_amd import synthetic as syn
+    wl = syn.make_workload("cfg2", batch=2)
+    ag = wl["agents"][0]
+    d, M = ag["dims"], ag["mats"]
+    rng = np.random.default_rng(3)
+    g = lambda mats, k, r, c: np.zeros((r, c)) if mats.get(k) is None or np.size(mats[k]) == 0 else np.asarray(mats[k], float).reshape(r, c)
+
+    def rows(mats, dd, x, u, dl, z, mu, om):
+        y = g(mats, "C", dd["ny"], dd["nx"]) @ x + g(mats, "D1", dd["ny"], dd["nu"]) @ u + g(mats, "D2", dd["ny"], dd["ndelta"]) @ dl + \
+            g(mats, "D3", dd["ny"], dd["nz"]) @ z + g(mats, "D4", dd["ny"], dd["nomega"]) @ om + g(mats, "d5", dd["ny"], 1)[:, 0]
+        con = (g(mats, "E", dd["nc"], dd["nx"]) @ x + g(mats, "F1", dd["nc"], dd["nu"]) @ u + g(mats, "F2", dd["nc"], dd["ndelta"]) @ dl +
+               g(mats, "F3", dd["nc"], dd["nz"]) @ z + g(mats, "F4", dd["nc"], dd["nomega"]) @ om + g(mats, "G", dd["nc"], dd["ny"]) @ y +
+               g(mats, "Psi", dd["nc"], dd["nmu"]) @ mu - g(mats, "f5", dd["nc"], 1)[:, 0])
+        x1 = g(mats, "A", dd["nx"], dd["nx"]) @ x + g(mats, "B1", dd["nx"], dd["nu"]) @ u + g(mats, "B2", dd["nx"], dd["ndelta"]) @ dl + \
+            g(mats, "B3", dd["nx"], dd["nz"]) @ z + g(mats, "B4", dd["nx"], dd["nomega"]) @ om + g(mats, "b5", dd["nx"], 1)[:, 0]
+        return con, x1
+    x, u, dl, z, mu, om = (rng.normal(size=d[k]) for k in ("nx", "nu", "ndelta", "nz", "nmu", "nomega"))
+    for unknown in (("delta", "z", "mu"), ("z", "mu"), ("mu",), ("delta",)):
+        m2, d2, known = fold_known(M, d, unknown)
+        assert d2["nu"] == 0 and known[0] == "u"
+        vals = dict(u=u, delta=dl, z=z, mu=mu)
+        om2 = np.concatenate([om] + [vals[k] for k in known])
+        assert om2.size == d2["nomega"]
+        e = np.zeros(0)
+        c2, x2 = rows(m2, d2, x, e, dl if "delta" in unknown else e, z if "z" in unknown else e, mu if "mu" in unknown else e, om2)
+        c1, x1 = rows(M, d, x, u, dl, z, mu, om)
+        assert np.allclose(c1, c2, rtol=0, atol=1e-9 * max(1.0, np.abs(c1).max()))
+        assert np.allclose(x1, x2, rtol=0, atol=1e-9 * max(1.0, np.abs(x1).max()))
+
+
+def test_lsim_k_argument_rules_and_sim_log_frame():
+    """ParNotSet / None rules of lsim_k (models/mld_model.py:647-683) that need no solve, and the DataFrame layout
+    of MldSimLog.get_concat_log (controllers/controller_base.py:116-146)"""
+    m = phc.MldModel(A=[[0.5]], B1=[[1.0]], B4=[[2.0]])
+    with pytest.raises(ValueError, match="omega_k"):
+        m.lsim_k(x_k=[1.0], u_k=[1.0])
+    with pytest.raises(ValueError, match="u_k"):
+        m.lsim_k(x_k=[1.0], omega_k=[0.0])
+    with pytest.raises(ValueError, match="not both"):
+        m.lsim_k(x_k=[1.0], v_k=[1.0], u_k=[1.0], omega_k=[0.0])
+    out = m.lsim_k(x_k=[2.0], u_k=None, omega_k=[1.0])                 # None means zeros
+    assert out["x_k1"][0, 0] == 3.0 and out["u"][0, 0] == 0.0
+    assert m.lsim_k(x_k=[2.0], v_k=[1.0], omega_k=[0.0])["x_k1"][0, 0] == 2.0
+    assert repr(phc.ParNotSet) == "ParNotSet" and not phc.ParNotSet
+    from pyhybridcontrol_amd.controllers import MldSimLog
+    log = MldSimLog()
+    log.set_sim_k(0, dict(x=[1.0, 2.0], u=[1.0]))
+    log[2] = dict(x=[3.0, 4.0])
+    log.update_sim_k(2, cost=5.0)
+    with pytest.raises(ValueError, match="shape"):
+        log.update_sim_k(2, x=[1.0])
+    with pytest.raises(TypeError):
+        log.update_sim_k(3, sim_k=[1, 2])
+    df = log.get_concat_log()
+    assert list(df.index) == [0, 2] and df.index.name == "k" and list(df.columns.names) == ["var_names", "var_index"]
+    assert df[("x", 1)].tolist() == [2.0, 4.0] and np.isnan(df[("u", 0)][2]) and np.isnan(df[("cost", 0)][0])
+    assert log.get_concat_log("mpc").columns[0] == ("mpc", "x", 0)
