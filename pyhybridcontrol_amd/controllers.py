@@ -193,6 +193,7 @@ class MpcController(object):
         self._mld_evo_matrices = None
         self._std_obj_atoms = ObjectiveAtoms(info.as_gpu_dims(), self._N_p, self._N_tilde)
         self._problem = None
+        self._epi_blocks, self._epi_sig, self._epi_dims, self._epi_model, self._vmap = [], (), None, None, None
         self._sense = 1.0
         self._solution = None
         self._x_k = np.zeros((info.nx, 1))
@@ -301,6 +302,7 @@ class MpcController(object):
             cols = om
         rows = N_t * info.n_constraints
         H_v = self.mld_evo_matrices.constraint["H_v_N_tilde"][:rows]
+        h = h[self._orig_rows(self._N_tilde * info.n_constraints)]
         return EvoConstraint(H_v, h[:rows].reshape(-1, 1), omega_cols=np.array(cols, dtype=np.float64), rows=rows,
                              x_is_parameter=x_is_parameter)
 
@@ -322,13 +324,49 @@ class MpcController(object):
             raise NotImplementedError("disable_soft_constraints (mu == 0) is not on the GPU path yet")
         self._build_required = True
 
+    def _epi_signature(self, blocks):
+        return tuple((b["var"], b["M"].shape, b["S"].shape, b["M"].tobytes()) for b in blocks)
+
+    def _problem_cost(self, cost):
+        """the cost dict in the layout of the GPU problem (epigraph auxiliaries appended when L1 / Linf atoms exist)"""
+        if not self._epi_blocks:
+            return cost
+        from . import epigraph
+        lifted, _ = epigraph.lift_cost(cost or {}, self._model.mld_info.as_gpu_dims(), self._epi_dims, self._N_tilde, self._epi_blocks)
+        return lifted
+
     def _ensure_problem(self):
+        blocks = self._std_obj_atoms.epigraph_blocks()
+        sig = self._epi_signature(blocks)
+        if self._problem is not None and sig != getattr(self, "_epi_sig", ()):
+            self._problem.close()                    # the set of epigraph atoms changed: another augmented model
+            self._problem = None
+            if getattr(self, "_epi_model", None) is not None:
+                self._epi_model.close()
+                self._epi_model = None
         if self._problem is None:
             evo = self.mld_evo_matrices
             cost = self._std_obj_atoms.to_cost()
             self._omega_atoms = cost.pop("_omega_atoms", [])
-            self._problem = gpu.GpuProblem(evo.gpu_model(), self._N_p, self._N_tilde, self._signed(cost), **self._solver_opts)
+            self._epi_blocks, self._epi_sig, self._vmap = blocks, sig, None
+            if blocks:
+                from . import epigraph
+                dims = self._model.mld_info.as_gpu_dims()
+                mats2, self._epi_dims, _ = epigraph.augment(self._model.as_mats(), dims, blocks)
+                self._epi_model = gpu.GpuModel([mats2], self._epi_dims)
+                lifted, self._vmap = epigraph.lift_cost(cost, dims, self._epi_dims, self._N_tilde, blocks)
+                self._problem = gpu.GpuProblem(self._epi_model, self._N_p, self._N_tilde, self._signed(lifted), **self._solver_opts)
+            else:
+                self._problem = gpu.GpuProblem(evo.gpu_model(), self._N_p, self._N_tilde, self._signed(cost), **self._solver_opts)
         return self._problem
+
+    def _orig_rows(self, n_rows):
+        """indices of the original constraint rows among the problem's rows (epigraph rows follow them in every step)"""
+        nc = self.mld_info_k.n_constraints
+        if not getattr(self, "_epi_blocks", None):
+            return np.arange(n_rows)
+        nc2 = self._epi_dims["nc"]
+        return np.concatenate([np.arange(k * nc2, k * nc2 + nc) for k in range(n_rows // nc)])
 
     def _signed(self, cost):
         return {k: (None if v is None else self._sense * np.asarray(v)) for k, v in cost.items()}
@@ -347,8 +385,12 @@ class MpcController(object):
             raise ValueError("Problem 'sense' must be either 'minimize' or 'maximize', got '%s'." % sense)
         cost = self._std_obj_atoms.to_cost() if with_std_objective else {}
         self._omega_atoms = cost.pop("_omega_atoms", []) if cost else []
-        if self._problem is None:
-            self._ensure_problem()
+        self._ensure_problem()
+        if self._epi_blocks and not with_std_objective:
+            raise NotImplementedError("with_std_objective=False while L1 / Linf atoms are set")
+        if self._epi_blocks and self._sense < 0:
+            raise ValueError("L1 / Linf atoms are convex: the problem cannot be maximised")
+        cost = self._problem_cost(cost) if cost else cost
         self._problem.set_cost(self._signed(cost) if cost else None)
         self._build_required = False
 
@@ -385,7 +427,9 @@ class MpcController(object):
                 cols = rows = None
                 if getattr(self, "_other_constraints", None):
                     cols = np.hstack([b.omega_cols for b in self._other_constraints]).T[np.newaxis]
-                    rows = np.concatenate([np.full(b.omega_cols.shape[1], b.rows) for b in self._other_constraints])
+                    nc = self.mld_info_k.n_constraints
+                    nc_p = self._epi_dims["nc"] if self._epi_blocks else nc
+                    rows = np.concatenate([np.full(b.omega_cols.shape[1], (b.rows // nc) * nc_p) for b in self._other_constraints])
                 out = self._problem.solve(self._x_k.T, self._omega_tilde_k.T, omega_cols=cols, col_rows=rows)
             except MldGpuError as e:
                 self._solve_time_solver = np.nan
@@ -397,7 +441,8 @@ class MpcController(object):
                 print("mldgpu: status=%s objective=%r nodes=%d pivots=%d" % (status, solution, out["nodes"][0], out["pivots"][0]))
             if not np.isfinite(solution):
                 raise ControllerSolverError("solve() failed with objective: '%s', and status: %s" % (solution, status))
-            self._solution = out["v"][0].reshape(-1, 1)
+            v = out["v"][0]
+            self._solution = (v if self._vmap is None else v[self._vmap]).reshape(-1, 1)
             self._status = status
             return solution
         finally:

@@ -4,8 +4,8 @@ Only what the MPC hot path needs: parsing the string keys
 ``<q|Q>[_Linear|_Quadratic|_L1|_L22|_Linf]_[d]<var>[_N_tilde|_N_p|_f]`` (:453-496), tiling per-step
 weights over the horizon (VectorWeight :76-137, MatrixWeight :140-206), dropping all-zero weights
 (:508,519-520), and turning Linear / Quadratic atoms (:308-331) into the tiled linear / quadratic
-weight arrays that libmldgpu's cost pull-back kernel (K4) consumes.  L1 / Linf / rate atoms are
-recognised and rejected with NotImplementedError.  This is string handling and
+weight arrays that libmldgpu's cost pull-back kernel (K4) consumes.  L1 / Linf atoms become epigraph rows of an
+augmented MLD model (epigraph.py); rate atoms are recognised and rejected with NotImplementedError.  This is string handling and
 array tiling -- no hot-path arithmetic happens here.
 """
 import re
@@ -168,9 +168,13 @@ class ObjectiveAtoms(object):
         const_omega = []
         for (var, atype, wtype, rate), w in self.weights.items():
             if rate:
-                raise NotImplementedError("rate ('d<var>') atoms need epigraph/lag variables: not on the GPU path yet")
-            if atype not in ("Linear", "Quadratic"):
-                raise NotImplementedError("%s atoms need epigraph variables: not on the GPU path yet" % atype)
+                raise NotImplementedError("rate ('d<var>') atoms need lag states: not on the GPU path yet")
+            if atype in ("L1", "Linf"):      # epigraph atoms: see epigraph_blocks() / epigraph.py (a model augmentation)
+                if var == "omega":
+                    raise NotImplementedError("%s atom on omega" % atype)
+                continue
+            if atype == "L22":               # L22ObjectiveAtom subclasses the quadratic atom (objective_atoms.py:347-348)
+                atype = "Quadratic"
             if atype == "Linear":            # w' var  /  sum(W var)          (objective_atoms.py:314-318)
                 lw = w[:, 0] if wtype == "vector" else w.sum(axis=0)
                 W = None
@@ -200,3 +204,8 @@ class ObjectiveAtoms(object):
         out = dict(lin_v=lin["v"], lin_x=lin["x"], lin_y=lin["y"], quad_v=quad["v"], quad_x=quad["x"], quad_y=quad["y"])
         out["_omega_atoms"] = const_omega
         return out
+
+    def epigraph_blocks(self):
+        """epigraph rows / auxiliaries the L1 and Linf atoms need (empty list when there are none)"""
+        from . import epigraph
+        return epigraph.plan(self.weights, self.dims, self.N_tilde)

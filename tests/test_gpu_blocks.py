@@ -133,3 +133,47 @@ def test_controller_scenario_and_minmax_blocks():
         ctrl.set_constraints(other_constraints=[object()])
     with pytest.raises(NotImplementedError):
         ctrl.set_constraints(other_constraints=[ctrl.gen_evo_constraints(x_k=[51.0])])
+
+
+def test_controller_l1_atoms_through_epigraph_augmentation():
+    """q_L1_* / Q_Linf_* atoms (controllers/components/objective_atoms.py:334-363) on the GPU: the controller solves the
+    epigraph-augmented MLD model and reports variables in the ORIGINAL layout; objective == linear part + the norms
+    evaluated on the returned point, and == HiGHS on the explicitly written problem."""
+    from scipy.optimize import milp, LinearConstraint, Bounds
+    model = phc.MldModel(A=[[0.9970371127900564]], B1=[[4.298192277481107]], B4=[[-179.73320827515]],
+                         b5=[[0.07407218024859108]], E=[[1], [-1]], F1=[[0], [0]], Psi=[[-1, 0], [0, -1]],
+                         f5=[[65.0], [-50.0]], nu_l=1, ts=900)
+    ctrl = phc.MpcController(model, N_p=4)
+    price = np.array([1, 3, 3, 1, 1.0])
+    w_x = 0.05
+    ctrl.set_std_obj_atoms(q_L1_u=(price * 0.75).reshape(-1, 1), q_mu=[90.0, 90.0], q_L1_x=w_x)
+    ctrl.build()
+    om = np.array([.004, .012, 0, .009, .002])
+    obj = ctrl.solve(0, x_k=[50.3], omega_tilde_k=om)
+    v = ctrl.v_N_tilde
+    assert v.shape == (15, 1)                                  # original layout [u; mu_top; mu_bot] x 5, no auxiliaries
+    x, _ = ctrl.predicted_trajectory()
+    u, mu = v.reshape(5, 3)[:, 0], v.reshape(5, 3)[:, 1:]
+    assert np.all((u == 0) | (u == 1))
+    expect = np.abs(price * 0.75 * u).sum() + 90.0 * mu.sum() + w_x * np.abs(x[:, 0]).sum()
+    assert abs(obj - expect) <= 1e-7 * max(1.0, abs(expect)), (obj, expect)
+    cons = ctrl.gen_evo_constraints()
+    assert cons.H_v.shape == (10, 15) and cons.rhs.shape == (10, 1)          # original rows only
+    assert np.all(cons.H_v @ v <= cons.rhs + 1e-7)
+    # the same problem written down directly (u >= 0, so |c u| = c u; |x| through explicit epigraph variables)
+    ev = cn.condense(model.as_mats(), 5)
+    xaff = ev["Phi_x"] @ np.array([50.3]) + ev["Gamma_omega"] @ om + ev["Gamma_5"][:, 0]
+    A = np.block([[ev["H_v"], np.zeros((10, 5))], [ev["Gamma_v"], -np.eye(5)], [-ev["Gamma_v"], -np.eye(5)]])
+    b = np.concatenate([cons.rhs[:, 0], -xaff, xaff])
+    c = np.concatenate([np.tile([0.0, 90.0, 90.0], 5) + np.kron(price * 0.75, [1.0, 0, 0]), np.full(5, w_x)])
+    lb = np.concatenate([np.zeros(15), np.full(5, -np.inf)]); ub = np.concatenate([np.tile([1.0, np.inf, np.inf], 5), np.full(5, np.inf)])
+    isb = np.concatenate([np.tile([1, 0, 0], 5), np.zeros(5)]).astype(int)
+    ref = milp(c, constraints=LinearConstraint(A, -np.inf, b), bounds=Bounds(lb, ub), integrality=isb)
+    assert ref.status == 0 and abs(obj - ref.fun) <= 1e-6 * max(1.0, abs(ref.fun)), (obj, ref.fun)
+    # dropping the L1 atoms rebuilds the plain problem (KAT objective 1.5)
+    ctrl.set_std_obj_atoms(q_u=(price * 0.75).reshape(-1, 1), q_mu=[90.0, 90.0])
+    ctrl.build()
+    assert abs(ctrl.solve(0, x_k=[50.3], omega_tilde_k=om) - 1.5) < 1e-9
+    ctrl.set_std_obj_atoms(q_L1_u=1.0, q_mu=[90.0, 90.0])
+    with pytest.raises(ValueError, match="maximised"):
+        ctrl.build(sense="maximize")
