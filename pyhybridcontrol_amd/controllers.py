@@ -320,12 +320,12 @@ class MpcController(object):
                 if not b.x_is_parameter:
                     raise NotImplementedError("constraint blocks generated with an explicit x_k")
             self._other_constraints = blocks
-        if disable_soft_constraints and self.mld_info_k.nmu:
-            raise NotImplementedError("disable_soft_constraints (mu == 0) is not on the GPU path yet")
+        # mu == 0 (controller_base.py:466-471): extra model rows mu <= 0, see epigraph.hard_block
+        self._no_soft = bool(disable_soft_constraints and self.mld_info_k.nmu)
         self._build_required = True
 
     def _epi_signature(self, blocks):
-        return tuple((b["var"], b["M"].shape, b["S"].shape, b["M"].tobytes()) for b in blocks)
+        return tuple((b["var"], b["M"].shape, b["S"].shape, b["M"].tobytes(), bool(b.get("one_sided"))) for b in blocks)
 
     def _problem_cost(self, cost):
         """the cost dict in the layout of the GPU problem (epigraph auxiliaries appended when L1 / Linf atoms exist)"""
@@ -337,6 +337,9 @@ class MpcController(object):
 
     def _ensure_problem(self):
         blocks = self._std_obj_atoms.epigraph_blocks()
+        if getattr(self, "_no_soft", False):
+            from . import epigraph
+            blocks = blocks + [epigraph.hard_block(self._model.mld_info.as_gpu_dims(), self._N_tilde)]
         sig = self._epi_signature(blocks)
         if self._problem is not None and sig != getattr(self, "_epi_sig", ()):
             self._problem.close()                    # the set of epigraph atoms changed: another augmented model
@@ -386,11 +389,12 @@ class MpcController(object):
         cost = self._std_obj_atoms.to_cost() if with_std_objective else {}
         self._omega_atoms = cost.pop("_omega_atoms", []) if cost else []
         self._ensure_problem()
-        if self._epi_blocks and not with_std_objective:
+        has_norms = any(not b.get("one_sided") for b in self._epi_blocks)
+        if has_norms and not with_std_objective:
             raise NotImplementedError("with_std_objective=False while L1 / Linf atoms are set")
-        if self._epi_blocks and self._sense < 0:
+        if has_norms and self._sense < 0:
             raise ValueError("L1 / Linf atoms are convex: the problem cannot be maximised")
-        cost = self._problem_cost(cost) if cost else cost
+        cost = self._problem_cost(cost) if (cost or self._epi_blocks) else cost
         self._problem.set_cost(self._signed(cost) if cost else None)
         self._build_required = False
 

@@ -53,11 +53,17 @@ def plan(weights, dims, N):
     return blocks
 
 
+def hard_block(dims, N):
+    """rows  mu <= 0  (with mu >= 0: mu == 0) -- `disable_soft_constraints` of controller_base.py:466-471 as model rows"""
+    k = dims["nmu"]
+    return dict(var="mu", M=np.eye(k), S=np.zeros((k, 0)), cost=np.zeros((N, 0)), one_sided=True)
+
+
 def augment(mats, dims, blocks):
     """(mats', dims', nt_total): the MLD system with the epigraph rows / auxiliaries of ``blocks`` appended"""
     nx, ny, nc, nz = dims["nx"], dims["ny"], dims["nc"], dims["nz"]
     nt = sum(b["S"].shape[1] for b in blocks)
-    nr = sum(2 * b["M"].shape[0] for b in blocks)
+    nr = sum((1 if b.get("one_sided") else 2) * b["M"].shape[0] for b in blocks)
 
     def get(name, r, c):
         a = mats.get(name)
@@ -79,10 +85,12 @@ def augment(mats, dims, blocks):
         name = _CON[b["var"]]
         col0 = 0
         new[name][r0:r0 + r, col0:col0 + M.shape[1]] += M           #  M var - S t <= 0
-        new[name][r0 + r:r0 + 2 * r, col0:col0 + M.shape[1]] -= M   # -M var - S t <= 0
         new["F3"][r0:r0 + r, t0:t0 + k] -= S
-        new["F3"][r0 + r:r0 + 2 * r, t0:t0 + k] -= S
-        r0 += 2 * r
+        r0 += r
+        if not b.get("one_sided"):
+            new[name][r0:r0 + r, col0:col0 + M.shape[1]] -= M       # -M var - S t <= 0
+            new["F3"][r0:r0 + r, t0:t0 + k] -= S
+            r0 += r
         t0 += k
     for k in con:
         out[k] = np.vstack([con[k], new[k]])

@@ -177,3 +177,22 @@ def test_controller_l1_atoms_through_epigraph_augmentation():
     ctrl.set_std_obj_atoms(q_L1_u=1.0, q_mu=[90.0, 90.0])
     with pytest.raises(ValueError, match="maximised"):
         ctrl.build(sense="maximize")
+
+
+def test_controller_disable_soft_constraints():
+    """build(disable_soft_constraints=True) (mpc_controller.py:76-101 -> controller_base.py:466-471): mu == 0"""
+    model = phc.MldModel(A=[[0.9970371127900564]], B1=[[4.298192277481107]], B4=[[-179.73320827515]],
+                         b5=[[0.07407218024859108]], E=[[1], [-1]], F1=[[0], [0]], Psi=[[-1, 0], [0, -1]],
+                         f5=[[65.0], [-50.0]], nu_l=1, ts=900)
+    ctrl = phc.MpcController(model, N_p=4)
+    price = np.array([1, 3, 3, 1, 1.0])
+    ctrl.set_std_obj_atoms(q_u=(price * 0.75).reshape(-1, 1), q_mu=[90.0, 90.0])
+    ctrl.build(disable_soft_constraints=True)
+    om = np.array([.004, .012, 0, .009, .002])
+    obj = ctrl.solve(0, x_k=[50.3], omega_tilde_k=om)
+    v = ctrl.v_N_tilde.reshape(5, 3)
+    assert abs(obj - 1.5) < 1e-9 and not v[:, 1:].any() and v.shape == (5, 3)
+    with pytest.raises(phc.ControllerSolverError):
+        ctrl.solve(0, x_k=[49.0], omega_tilde_k=om)            # below the lower limit: only the slack made this feasible
+    ctrl.build()                                                # soft again
+    assert np.isfinite(ctrl.solve(0, x_k=[49.0], omega_tilde_k=om)) and ctrl.v_N_tilde.reshape(5, 3)[:, 1:].sum() > 0
