@@ -9,8 +9,9 @@ with the same method names, argument meaning and error behaviour:
 ``build()`` -> problem on the GPU; ``solve()`` -> objective value (float) or ControllerSolverError;
 ``feedback()`` -> variables at step k; ``sim_step_k()`` -> plant step + log; ``external_solve``
 bypasses the backend (controller_base.py:507,536-538).  Where the reference builds cvxpy expressions,
-this keeps numeric arrays.  Unsupported reference features raise NotImplementedError loudly
-(extra constraint blocks, disable_soft_constraints, L1/Linf/rate atoms, time-varying horizons).
+this keeps numeric arrays.  Scenario / min-max constraint blocks, disable_soft_constraints and L1 / Linf atoms run on
+the same kernels (row-min right-hand sides, model augmentation); unsupported reference features raise
+NotImplementedError loudly (rate atoms, time-varying horizons, custom standard constraints).
 """
 import time
 
