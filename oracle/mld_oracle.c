@@ -1068,8 +1068,20 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                                     if (sa * t->rs[i] > 1e-6) feas = 0;
                                 }
                                 if (feas && ob < best) { best = ob; have = 1; memcpy(x_out, xo, sizeof(double) * n); }
+                                leaf_ok = feas;
                             }
                             for (int k = 0; k < ns; ++k) set_bounds(t, sv_j[k], sv_lo[k], sv_hi[k]);
+                            if (!leaf_ok) {
+                                /* The rounded point is not feasible although every binary is within the integrality
+                                 * tolerance: with big-M rows a binary at 1e-6 can carry a whole unit of the row.  The
+                                 * node is then NOT a leaf -- branch on the least integral free binary. */
+                                double fbest = 1e-12;
+                                for (int k = 0; k < nb; ++k) {
+                                    const int j = bins[k];
+                                    const double f = fabs(xs[j] - rint(xs[j]));
+                                    if (t->lo[j] != t->hi[j] && f > fbest) { fbest = f; branch_j = j; branch_x = xs[j]; }
+                                }
+                            }
                         }
                     }
                 }
