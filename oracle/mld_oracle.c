@@ -1131,7 +1131,9 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
             if (finished) { if (!rescue) status = ORC_OPTIMAL; break; }
             if (lp == LP_ITERLIMIT) break;
             if (phase == PH_IDS && limit && !have && !rescue && nodes < o->max_nodes) {
-                phase = PH_DIVE; limit = 0; T = INFINITY; node_budget = o->max_nodes; continue;
+                /* the dive may finish even when it outlasts the node budget (it is what guarantees a feasible point) */
+                phase = PH_DIVE; limit = 0; T = INFINITY;
+                node_budget = o->max_nodes > nodes + 3 * nb + 10 ? o->max_nodes : nodes + 3 * nb + 10; continue;
             }
             if (phase == PH_DIVE) {
                 limit = nodes >= o->max_nodes;

@@ -14,4 +14,8 @@ secs = tel["rows_updated"].sum()
 print("n", p.n, "sectors updated", secs, "bytes %.3e" % (secs * 128.0), "GB/s %.1f" % (secs * 128.0 / st["solve_ms"] / 1e6),
       "pivots/s %.0f" % (st["pivots"] / st["solve_ms"] * 1e3), "solves/s %.1f" % (B / st["solve_ms"] * 1e3))
 lim = out["status"] == 2
-if lim.any(): print("median gap of limited", np.median((out["obj"][lim] - out["lower_bound"][lim]) / np.abs(out["obj"][lim])))
+fin = np.isfinite(out["obj"])
+print("no incumbent", int((~fin).sum()), "numerical idx", np.where(out["status"] == 3)[0][:5])
+if (lim & fin).any():
+    g = (out["obj"][lim & fin] - out["lower_bound"][lim & fin]) / np.abs(out["obj"][lim & fin])
+    print("gap of limited: median %.4f p90 %.4f max %.4f" % (np.median(g), np.percentile(g, 90), g.max()))
