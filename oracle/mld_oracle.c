@@ -1032,6 +1032,21 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                         for (int r = 0; r < t->m; ++r) if (t->basic[r] < n) xs[t->basic[r]] = t->xB[r];
                         }
                         if (nodes == 1) for (int k = 0; k < nb; ++k) xroot[k] = xs[bins[k]];
+                        if (depth == 0 && have && (phase == PH_IDS || phase == PH_FINAL) && !t->P) {
+                            /* reduced-cost fixing at the true root (no temporary fixings active): a non-basic binary whose
+                             * reduced cost exceeds the room below the cutoff cannot leave its bound in any solution that
+                             * still matters; the fixing is permanent */
+                            const double *dd = t->D + (size_t)t->mcap * t->ld;
+                            const double room = inc_cut - obj;
+                            int nfx = 0;
+                            for (int c = 0; c < n; ++c) {
+                                const int j = t->nonbasic[c];
+                                if (j >= n || !is_bin[j] || t->lo[j] == t->hi[j]) continue;
+                                const double rc = t->at_upper[c] ? -dd[c] : dd[c];
+                                if (rc > room + 1e-9) { const double v = t->xN[c]; root_lo[j] = root_hi[j] = v; set_bounds(t, j, v, v); nfx++; }
+                            }
+                            if (getenv("ORC_DEBUG")) fprintf(stderr, "  rc-fixed %d (room %.6g)\n", nfx, room);
+                        }
                         if (phase == PH_DIVE) {   /* fractional binary closest to 1 (first such index) */
                             double bv = -1.0;
                             for (int k = 0; k < nb; ++k) {
