@@ -37,7 +37,9 @@ typedef enum {
     MLD_STATUS_OPTIMAL = 0,
     MLD_STATUS_INFEASIBLE = 1,
     MLD_STATUS_NODE_LIMIT = 2, /* incumbent (if any) returned, gap = obj - lower_bound */
-    MLD_STATUS_NUMERICAL = 3
+    MLD_STATUS_NUMERICAL = 3,
+    MLD_STATUS_UNBOUNDED = 4   /* a free variable rests on the solver's artificial box: objective -inf, the ray's point in v_out
+                                  (counted under n_numerical in mld_stats) */
 } mld_status;
 
 /* MLD dimensions, models/mld_model.py:149-168 (MldInfo._mld_dim_map): nv = nu+ndelta+nz+nmu;

@@ -38,7 +38,7 @@
 #define ORC_COEF_ZERO 1e-9
 #define ORC_RESID_TOL 1e-6
 
-enum { ORC_OPTIMAL = 0, ORC_INFEASIBLE = 1, ORC_NODE_LIMIT = 2, ORC_NUMERICAL = 3 };
+enum { ORC_OPTIMAL = 0, ORC_INFEASIBLE = 1, ORC_NODE_LIMIT = 2, ORC_NUMERICAL = 3, ORC_UNBOUNDED = 4 };
 enum { LP_OPTIMAL = 0, LP_INFEASIBLE = 1, LP_CUTOFF = 2, LP_ITERLIMIT = 3 };
 
 typedef struct {
@@ -980,7 +980,7 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
         enum { PH_IDS = 0, PH_DIVE, PH_RINS, PH_FINAL };
         const double root_bound = st->root_bound;
         int nodes = 0, limit = 0, pass = 0, rescue = 0, node_budget = o->max_nodes;
-        int phase = PH_IDS, rins_rounds = 0, nfix = 0;
+        int phase = PH_IDS, rins_rounds = 0, nfix = 0, unbounded = 0;
         const int ids_cap = o->max_nodes / 4 > 16 ? o->max_nodes / 4 : 16;
         const double dive_tol = 1e-2 * fmax(1.0, fabs(root_bound));
         double *xroot = dalloc(nb + 1), *fx_lo = dalloc(nb + 1), *fx_hi = dalloc(nb + 1);
@@ -1083,6 +1083,9 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                                     if (sa * t->rs[i] > 1e-6) feas = 0;
                                 }
                                 if (feas && ob < best) { best = ob; have = 1; memcpy(x_out, xo, sizeof(double) * n); }
+                                if (feas)   /* a free variable resting on the artificial box (+-ORC_BIG, scaled): no finite optimum */
+                                    for (int j = 0; j < n; ++j)
+                                        if ((lb[j] == -INFINITY && xo[j] / t->cs[j] <= -0.999 * ORC_BIG) || (ub[j] == INFINITY && xo[j] / t->cs[j] >= 0.999 * ORC_BIG)) unbounded = 1;
                                 leaf_ok = feas;
                             }
                             for (int k = 0; k < ns; ++k) set_bounds(t, sv_j[k], sv_lo[k], sv_hi[k]);
@@ -1100,7 +1103,7 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                         }
                     }
                 }
-                if (have && (rescue || best <= root_bound + gtol(o, best))) { finished = 1; }
+                if (have && (rescue || unbounded || best <= root_bound + gtol(o, best))) { finished = 1; }
                 if (nodes >= ((phase == PH_IDS && !have && !rescue) ? ids_cap : node_budget)) limit = 1;
                 if (phase == PH_DIVE && !limit && !finished) {
                     /* no backtracking: the dive ends at its first leaf, or when the node is infeasible */
@@ -1143,7 +1146,7 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                 for (int k = 0; k < nfix; ++k) { const int j = fx_j[k]; root_lo[j] = fx_lo[k]; root_hi[j] = fx_hi[k]; set_bounds(t, j, fx_lo[k], fx_hi[k]); }
                 rins_rounds++;
             }
-            if (finished) { if (!rescue) status = ORC_OPTIMAL; break; }
+            if (finished) { if (unbounded) { status = ORC_UNBOUNDED; best = -INFINITY; } else if (!rescue) status = ORC_OPTIMAL; break; }
             if (lp == LP_ITERLIMIT) break;
             if (phase == PH_IDS && limit && !have && !rescue && nodes < o->max_nodes) {
                 /* the dive may finish even when it outlasts the node budget (it is what guarantees a feasible point) */

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "_build", "libmldoracle.so")
 
-STATUS = {0: "optimal", 1: "infeasible", 2: "node_limit", 3: "numerical"}
+STATUS = {0: "optimal", 1: "infeasible", 2: "node_limit", 3: "numerical", 4: "unbounded"}
 MAT_NAMES = ("A", "B1", "B2", "B3", "B4", "b5", "C", "D1", "D2", "D3", "D4", "d5",
              "E", "F1", "F2", "F3", "F4", "f5", "G", "Psi")
 
@@ -74,7 +74,7 @@ def solve_milp(q, G, h, lb, ub, is_bin, **kw):
     o = make_opts(**kw)
     s = lib().orc_solve_milp(n, m, _p(q), _p(G), _p(h), _p(lb), _p(ub), ib.ctypes.data_as(C.POINTER(C.c_ubyte)),
                              C.byref(o), _p(x), C.byref(obj), C.byref(st))
-    return dict(status=STATUS[s], obj=obj.value, x=x if np.isfinite(obj.value) else None, nodes=st.nodes,
+    return dict(status=STATUS[s], obj=obj.value, x=x if (np.isfinite(obj.value) or s == 4) else None, nodes=st.nodes,
                 pivots=st.pivots, cuts=st.cuts, refactors=st.refactors, root_lp=st.root_lp,
                 root_bound=st.root_bound, lower_bound=st.lower_bound)
 
@@ -96,7 +96,7 @@ def solve_miqp(P, q, G, h, lb, ub, is_bin, **kw):
     lib().orc_solve_miqp.restype = C.c_int
     s = lib().orc_solve_miqp(n, m, _p(P), _p(q), _p(G), _p(h), _p(lb), _p(ub), ib.ctypes.data_as(C.POINTER(C.c_ubyte)),
                              C.byref(o), _p(x), C.byref(obj), C.byref(st))
-    return dict(status=STATUS[s], obj=obj.value, x=x if np.isfinite(obj.value) else None, nodes=st.nodes,
+    return dict(status=STATUS[s], obj=obj.value, x=x if (np.isfinite(obj.value) or s == 4) else None, nodes=st.nodes,
                 pivots=st.pivots, cuts=st.cuts, refactors=st.refactors, root_lp=st.root_lp,
                 root_bound=st.root_bound, lower_bound=st.lower_bound)
 

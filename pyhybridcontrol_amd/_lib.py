@@ -15,7 +15,7 @@ MAT_NAMES = ("A", "B1", "B2", "B3", "B4", "b5", "C", "D1", "D2", "D3", "D4", "d5
              "E", "F1", "F2", "F3", "F4", "f5", "G", "Psi")
 EVO_NAMES = ("Phi_x", "Gamma_v", "Gamma_omega", "Gamma_5", "L_x", "L_v", "L_omega", "L_5",
              "H_x", "H_v", "H_omega", "H_5")
-STATUS_NAMES = {0: "optimal", 1: "infeasible", 2: "node_limit", 3: "numerical"}
+STATUS_NAMES = {0: "optimal", 1: "infeasible", 2: "node_limit", 3: "numerical", 4: "unbounded"}
 COMM_ID_BYTES = 128
 
 

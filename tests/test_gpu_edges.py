@@ -1,0 +1,88 @@
+"""Edge shapes through the C ABI: no binaries (pure LP), no disturbance, a single instance, an unbounded problem, a model
+without constraints, batches larger than the number of solver slots with a ragged tail."""
+import numpy as np
+import pytest
+from scipy.optimize import linprog
+
+import condense_np as cn
+import pyhybridcontrol_amd as phc
+from pyhybridcontrol_amd import gpu, host
+
+pytestmark = pytest.mark.gpu
+
+
+def _lp_reference(mats, d, atoms, N_p, N, x0, om):
+    sf = cn.standard_form(mats, atoms, N_p, N, nu_l=d.get("nu_l", 0))
+    h = cn.rhs(sf["evo"], x0, om)
+    q = cn.lin_cost(sf["cost"], x0, om)
+    r0 = cn.cost_const(sf["cost"]["const_terms"], x0, om)
+    res = linprog(q, A_ub=sf["G"], b_ub=h, bounds=np.c_[sf["lb"], sf["ub"]], method="highs")
+    return res, r0
+
+
+def test_pure_lp_model_no_binaries_no_disturbance():
+    # double integrator, continuous input in [-1, 1] through constraint rows, soft position limit; no omega, no binaries
+    mats = dict(A=[[1.0, 0.1], [0.0, 1.0]], B1=[[0.005], [0.1]],
+                E=[[0, 0], [0, 0], [1.0, 0], [-1.0, 0]], F1=[[1.0], [-1.0], [0], [0]],
+                Psi=[[0, 0], [0, 0], [-1.0, 0], [0, -1.0]], f5=[[1.0], [1.0], [2.0], [2.0]])
+    d = dict(nx=2, nu=1, ndelta=0, nz=0, nmu=2, nomega=0, ny=2, nc=4, nu_l=0, nmu_l=0)
+    mats["C"] = np.eye(2)
+    N_p, N = 9, 10
+    atoms = {"q_mu": [100.0, 100.0], "q_x": [1.0, 0.1], "q_u": 0.01}
+    m = gpu.GpuModel([mats], d)
+    p = gpu.GpuProblem(m, N_p, N, host.cost_from_atoms(atoms, d, N_p, N))
+    assert p.n_bin == 0
+    X0 = np.array([[1.5, 0.0], [-1.0, 2.0], [0.0, 0.0]])
+    out = p.solve(X0, np.zeros((3, 0)))
+    for s in range(3):
+        ref, r0 = _lp_reference(mats, d, atoms, N_p, N, X0[s], np.zeros(0))
+        assert ref.status == 0 and out["status"][s] == 0 and out["nodes"][s] == 1
+        assert abs(out["obj"][s] - (ref.fun + r0)) <= 1e-6 * max(1.0, abs(ref.fun + r0)), (s, out["obj"][s], ref.fun + r0)
+    one = p.solve(X0[:1], np.zeros((1, 0)))                       # a single instance
+    assert one["obj"][0] == out["obj"][0]
+    p.close(); m.close()
+
+
+def test_unbounded_and_unconstrained_models_report_status_not_crash():
+    # cost pushes a free continuous input to -inf: no finite optimum -> UNBOUNDED, objective -inf, no exception
+    mats = dict(A=[[1.0]], B1=[[1.0]], E=[[1.0]], F1=[[0.0]], f5=[[10.0]])
+    d = dict(nx=1, nu=1, ndelta=0, nz=0, nmu=0, nomega=0, ny=1, nc=1, nu_l=0, nmu_l=0)
+    m = gpu.GpuModel([mats], d)
+    p = gpu.GpuProblem(m, 2, 3, host.cost_from_atoms({"q_u": 1.0}, d, 2, 3))
+    out = p.solve(np.zeros((2, 1)), np.zeros((2, 0)))
+    assert np.all(out["status"] == 4) and np.all(out["obj"] == -np.inf) and gpu._lib.STATUS_NAMES[4] == "unbounded"
+    p.close(); m.close()
+    ctrl = phc.MpcController(phc.MldModel(mats), N_p=2)              # the controller raises, like the reference on a non-finite objective
+    ctrl.set_std_obj_atoms(q_u=1.0)
+    ctrl.build()
+    with pytest.raises(phc.ControllerSolverError, match="unbounded"):
+        ctrl.solve(0, x_k=[0.0])
+    # a model without constraint rows and a binary input: the cost alone decides (u = 0 for q_u > 0)
+    model = phc.MldModel(A=[[0.5]], B1=[[1.0]], nu_l=1)
+    ctrl = phc.MpcController(model, N_p=2)
+    ctrl.set_std_obj_atoms(q_u=2.0)
+    ctrl.build()
+    assert ctrl.solve(0, x_k=[1.0]) == 0.0 and not ctrl.v_N_tilde.any()
+    assert ctrl.gen_evo_constraints().rhs.shape == (0, 1)
+
+
+def test_batch_larger_than_slots_with_ragged_tail_matches_single_solves():
+    """n_slots forced small so that the work queue wraps many times and the last round is partial; every instance
+    must equal its own single-instance solve (bit for bit)"""
+    from pyhybridcontrol_amd import synthetic as syn
+    wl = syn.make_workload("cfg2", batch=37)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    m = gpu.GpuModel([ag["mats"]], d)
+    cost = host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"])
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost, max_nodes=300, n_slots=5)
+    out = p.solve(ag["x0"], ag["omega"])
+    again = p.solve(ag["x0"], ag["omega"])                           # second solve uses the longest-first order
+    assert np.array_equal(out["obj"], again["obj"]) and np.array_equal(out["v"], again["v"])
+    q = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost, max_nodes=300)
+    for s in (0, 17, 36):
+        one = q.solve(ag["x0"][s:s + 1], ag["omega"][s:s + 1])
+        assert one["obj"][0] == out["obj"][s] and np.array_equal(one["v"][0], out["v"][s]) and one["status"][0] == out["status"][s]
+    with pytest.raises(phc.MldGpuError):
+        p.solve(ag["x0"], ag["omega"], model_idx=np.full(37, 3, np.int32))     # model index out of range
+    p.close(); q.close(); m.close()

@@ -264,7 +264,11 @@ def test_mpc_controller_end_to_end_known_answer():
     with pytest.raises(phc.ControllerBuildRequiredError):
         ctrl.solve(1)
     ctrl.build(sense="maximize")
-    assert np.isfinite(ctrl.solve(1, MIPGap=1e-2))
+    with pytest.raises(phc.ControllerSolverError, match="unbounded"):      # max 90 mu has no finite value
+        ctrl.solve(1, MIPGap=1e-2)
+    ctrl.set_std_obj_atoms(q_u=price.reshape(-1, 1))
+    ctrl.build(sense="maximize")
+    assert abs(ctrl.solve(1, MIPGap=1e-2) - price.sum()) < 1e-9 and np.all(ctrl.v_N_tilde.reshape(5, 3)[:, 0] == 1)
     # an infeasible instance -> ControllerSolverError (hard bound instead of the soft one)
     hard = phc.MldModel(A=[[1.0]], B1=[[0.0]], E=[[1.0], [-1.0]], F1=[[0.0], [0.0]], f5=[[1.0], [-2.0]], nu_l=1)
     c2 = phc.MpcController(hard, N_p=1)

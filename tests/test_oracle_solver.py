@@ -172,3 +172,14 @@ def test_miqp_with_zero_hessian_equals_milp():
     a = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], presolve=0)
     b = orc.solve_miqp(np.zeros((q.size, q.size)), q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], presolve=0)
     assert a["status"] == b["status"] == "optimal" and abs(a["obj"] - b["obj"]) <= 1e-8 * max(1, abs(a["obj"]))
+
+
+def test_unbounded_problem_is_reported_not_boxed():
+    """a free variable with a cost and no bound in its direction: status 'unbounded', objective -inf (the solver boxes free
+    variables at +-1e7 internally; resting on that box must not be reported as an optimum)"""
+    r = orc.solve_milp(np.array([1.0, 0.0]), np.array([[0.0, 1.0]]), np.array([1.0]), np.array([-np.inf, 0.0]),
+                       np.array([np.inf, 1.0]), np.array([0, 1], np.uint8))
+    assert r["status"] == "unbounded" and r["obj"] == -np.inf
+    r = orc.solve_milp(np.array([1.0, 0.0]), np.array([[-1.0, 1.0]]), np.array([1.0]), np.array([-np.inf, 0.0]),
+                       np.array([np.inf, 1.0]), np.array([0, 1], np.uint8))       # x >= y - 1 bounds it: optimum -1 at y = 0
+    assert r["status"] == "optimal" and abs(r["obj"] + 1.0) < 1e-9
