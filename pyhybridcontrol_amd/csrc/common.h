@@ -45,6 +45,9 @@ struct mld_model {
     size_t mat_size[20];
     int mat_rows[20], mat_cols[20];
     std::vector<std::vector<double>> h_mats;   // host copies (needed by the big-M tightening)
+    double *d_pack;       // per model, packed once at creation in the LDS order of k_condense_blocks:
+                          // A, B4, b5, C, D4, d5, E, F4, f5, G, [B1 B2 B3 0], [D1 D2 D3 0], [F1 F2 F3 Psi]
+    size_t pack_len;
     // condensing results (device resident)
     int cond_N;
     CondLayout lay;

@@ -75,7 +75,7 @@ int mld_model_create(mld_model_t **out, const mld_dims *dims, int n_models, cons
     if (mld_device_count() <= 0) { mld_set_error("no HIP device (libmldgpu has no CPU fallback)"); return MLD_ERR_NO_DEVICE; }
     mld_model *m = new mld_model();
     m->dims = d; m->n_models = n_models; m->nv = d.nu + d.ndelta + d.nz + d.nmu;
-    m->cond_N = -1; m->d_blocks = nullptr;
+    m->cond_N = -1; m->d_blocks = nullptr; m->d_pack = nullptr; m->pack_len = 0;
     for (int k = 0; k < 12; ++k) m->d_out[k] = nullptr;
     m->h_mats.resize(20);
     for (int k = 0; k < 20; ++k) {
@@ -92,6 +92,43 @@ int mld_model_create(mld_model_t **out, const mld_dims *dims, int n_models, cons
         if (e == hipSuccess) e = hipMemcpy(m->d_mats[k], m->h_mats[k].data(), sizeof(double) * tot, hipMemcpyHostToDevice);
         if (e != hipSuccess) { mld_set_error("mld_model_create: %s", hipGetErrorString(e)); mld_model_destroy(m); return MLD_ERR_HIP; }
     }
+    {   // every per-step matrix the block kernel needs, packed per model in its LDS order (one coalesced sweep instead of
+        // thirteen dependent small copies); the input matrices are stacked horizontally as in mld_evolution_matrices.py:291,355,411
+        const int nv = m->nv;
+        const int plain[10] = {MT_A, MT_B4, MT_b5, MT_C, MT_D4, MT_d5, MT_E, MT_F4, MT_f5, MT_G};
+        const int rws[3] = {d.nx, d.ny, d.nc};
+        const int ids[3][4] = {{MT_B1, MT_B2, MT_B3, -1}, {MT_D1, MT_D2, MT_D3, -1}, {MT_F1, MT_F2, MT_F3, MT_Psi}};
+        const int cw[4] = {d.nu, d.ndelta, d.nz, d.nmu};
+        size_t len = 0;
+        for (int k = 0; k < 10; ++k) len += m->mat_size[plain[k]];
+        for (int f = 0; f < 3; ++f) len += (size_t)rws[f] * nv;
+        m->pack_len = len;
+        if (len) {
+            std::vector<double> pack(len * n_models, 0.0);
+            for (int mdl = 0; mdl < n_models; ++mdl) {
+                double *dst = pack.data() + (size_t)mdl * len;
+                for (int k = 0; k < 10; ++k) {
+                    const size_t sz = m->mat_size[plain[k]];
+                    if (sz) memcpy(dst, m->h_mats[plain[k]].data() + (size_t)mdl * sz, sizeof(double) * sz);
+                    dst += sz;
+                }
+                for (int f = 0; f < 3; ++f) {
+                    int o = 0;
+                    for (int g = 0; g < 4; ++g) {
+                        if (ids[f][g] >= 0 && cw[g])
+                            for (int i = 0; i < rws[f]; ++i)
+                                for (int c = 0; c < cw[g]; ++c)
+                                    dst[(size_t)i * nv + o + c] = m->h_mats[ids[f][g]][(size_t)mdl * rws[f] * cw[g] + (size_t)i * cw[g] + c];
+                        o += cw[g];
+                    }
+                    dst += (size_t)rws[f] * nv;
+                }
+            }
+            hipError_t e = hipMalloc(&m->d_pack, sizeof(double) * pack.size());
+            if (e == hipSuccess) e = hipMemcpy(m->d_pack, pack.data(), sizeof(double) * pack.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { mld_set_error("mld_model_create: %s", hipGetErrorString(e)); mld_model_destroy(m); return MLD_ERR_HIP; }
+        }
+    }
     *out = m;
     return MLD_OK;
 }
@@ -101,6 +138,7 @@ int mld_model_destroy(mld_model_t *m)
     if (!m) return MLD_OK;
     for (int k = 0; k < 20; ++k) if (m->d_mats[k]) (void)hipFree(m->d_mats[k]);
     if (m->d_blocks) (void)hipFree(m->d_blocks);
+    if (m->d_pack) (void)hipFree(m->d_pack);
     for (int k = 0; k < 12; ++k) if (m->d_out[k]) (void)hipFree(m->d_out[k]);
     delete m;
     return MLD_OK;
