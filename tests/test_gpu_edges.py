@@ -86,3 +86,28 @@ def test_batch_larger_than_slots_with_ragged_tail_matches_single_solves():
     with pytest.raises(phc.MldGpuError):
         p.solve(ag["x0"], ag["omega"], model_idx=np.full(37, 3, np.int32))     # model index out of range
     p.close(); q.close(); m.close()
+
+
+def test_c_abi_argument_validation_returns_errors_not_faults():
+    import ctypes as C
+    from pyhybridcontrol_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    bad = _lib.Dims(nx=1, nu=1, ndelta=0, nz=0, nmu=0, nomega=0, ny=1, nc=0, nu_l=2, nmu_l=0)        # nu_l > nu
+    ptrs = (C.POINTER(C.c_double) * 20)()
+    assert lib.mld_model_create(C.byref(h), C.byref(bad), 1, ptrs) == -1 and b"dimensions" in lib.mld_last_error()
+    assert lib.mld_model_create(C.byref(h), None, 1, ptrs) == -1
+    model = gpu.GpuModel([dict(A=[[0.5]], B1=[[1.0]], E=[[1.0]], F1=[[0.0]], f5=[[3.0]])],
+                         dict(nx=1, nu=1, ndelta=0, nz=0, nmu=0, nomega=0, ny=1, nc=1, nu_l=1, nmu_l=0))
+    with pytest.raises(phc.MldGpuError):
+        gpu.GpuProblem(model, 2, 0)                                  # N_tilde < 1
+    p = gpu.GpuProblem(model, 1, 2, host.cost_from_atoms({"q_u": 1.0}, model.dims, 1, 2))
+    with pytest.raises(phc.MldGpuError, match="upload"):
+        p.solve_resident()                                           # nothing uploaded
+    assert lib.mld_upload_constraint_blocks(p._h, 1, None, None) != 0     # before any upload
+    p.upload(np.zeros((2, 1)), np.zeros((2, 0)))
+    assert lib.mld_upload_batch(p._h, 0, None, None, None, None) == -1
+    out = p.solve(np.array([[1.0], [2.0]]), np.zeros((2, 0)))
+    assert np.all(out["status"] == 0) and np.all(out["obj"] == 0.0)
+    assert lib.mld_download_results(None, None, None, None, None, None, None) == -1
+    p.close(); model.close()
