@@ -9,9 +9,9 @@ with the same method names, argument meaning and error behaviour:
 ``build()`` -> problem on the GPU; ``solve()`` -> objective value (float) or ControllerSolverError;
 ``feedback()`` -> variables at step k; ``sim_step_k()`` -> plant step + log; ``external_solve``
 bypasses the backend (controller_base.py:507,536-538).  Where the reference builds cvxpy expressions,
-this keeps numeric arrays.  Scenario / min-max constraint blocks, disable_soft_constraints and L1 / Linf atoms run on
+this keeps numeric arrays.  Scenario / min-max constraint blocks, disable_soft_constraints, L1 / Linf and rate atoms run on
 the same kernels (row-min right-hand sides, model augmentation); unsupported reference features raise
-NotImplementedError loudly (rate atoms, time-varying horizons, custom standard constraints).
+NotImplementedError loudly (rate atoms on mu, time-varying horizons, custom standard constraints).
 """
 import time
 
@@ -195,6 +195,7 @@ class MpcController(object):
         self._std_obj_atoms = ObjectiveAtoms(info.as_gpu_dims(), self._N_p, self._N_tilde)
         self._problem = None
         self._epi_blocks, self._epi_sig, self._epi_dims, self._epi_model, self._vmap = [], (), None, None, None
+        self._rate_vars, self._rate_info, self._rate_dims, self._k_neg1 = [], {}, None, {}
         self._sense = 1.0
         self._solution = None
         self._x_k = np.zeros((info.nx, 1))
@@ -293,13 +294,13 @@ class MpcController(object):
             Om = np.asarray(omega_scenarios_k, dtype=np.float64)
             if Om.shape[0] == N_t * info.nomega and N_t < self._N_tilde:
                 Om = np.vstack([Om, np.zeros(((self._N_tilde - N_t) * info.nomega, Om.shape[1]))])
-            h = prob.rhs(x_k.T, Om.T[np.newaxis], scenarios=Om.shape[1])[0]
+            h = prob.rhs(self._x_problem(x_k).T, Om.T[np.newaxis], scenarios=Om.shape[1])[0]
             cols = Om
         else:
             om = self._omega_tilde_k if omega_tilde_k is None else atleast_2d_col(omega_tilde_k)
             if om.shape[0] == N_t * info.nomega and N_t < self._N_tilde:
                 om = np.vstack([om, np.zeros(((self._N_tilde - N_t) * info.nomega, 1))])
-            h = prob.rhs(x_k.T, om.T)[0]
+            h = prob.rhs(self._x_problem(x_k).T, om.T)[0]
             cols = om
         rows = N_t * info.n_constraints
         H_v = self.mld_evo_matrices.constraint["H_v_N_tilde"][:rows]
@@ -328,22 +329,48 @@ class MpcController(object):
     def _epi_signature(self, blocks):
         return tuple((b["var"], b["M"].shape, b["S"].shape, b["M"].tobytes(), bool(b.get("one_sided"))) for b in blocks)
 
-    def _problem_cost(self, cost):
-        """the cost dict in the layout of the GPU problem (epigraph auxiliaries appended when L1 / Linf atoms exist)"""
-        if not self._epi_blocks:
-            return cost
+    def _augmentation(self):
+        """(mats', dims', blocks, rate variables, rate info): the MLD model the GPU problem is built from.  Rate atoms add
+        lag states and rate outputs (epigraph.augment_rates), L1 / Linf atoms and disable_soft_constraints add rows and
+        auxiliaries (epigraph.augment); without any of them it is the controller's own model."""
         from . import epigraph
-        lifted, _ = epigraph.lift_cost(cost or {}, self._model.mld_info.as_gpu_dims(), self._epi_dims, self._N_tilde, self._epi_blocks)
+        W = self._std_obj_atoms.weights
+        dims0, N = self._model.mld_info.as_gpu_dims(), self._N_tilde
+        rv = epigraph.rate_vars(W)
+        mats1, dims1, info = epigraph.augment_rates(self._model.as_mats(), dims0, rv) if rv else (self._model.as_mats(), dims0, {})
+        blocks = epigraph.plan(W, dims0, N)
+        for b in blocks:                      # atoms on x / y act on the original entries, not on lag states / rate outputs
+            if b["var"] in ("x", "y"):
+                width = dims1["nx"] if b["var"] == "x" else dims1["ny"]
+                b["M"] = np.hstack([b["M"], np.zeros((b["M"].shape[0], width - b["M"].shape[1]))])
+        return mats1, dims1, blocks, rv, info
+
+    def _problem_cost(self, cost):
+        """the cost dict in the layouts of the GPU problem (lag states / rate outputs / epigraph auxiliaries appended)"""
+        from . import epigraph
+        if not (self._epi_blocks or self._rate_vars):
+            return cost
+        dims0, N = self._model.mld_info.as_gpu_dims(), self._N_tilde
+        c = epigraph.lift_xy_cost(cost or {}, dims0, self._rate_dims, N)
+        if self._rate_vars:
+            epigraph.rate_cost_and_blocks(self._std_obj_atoms.weights, self._rate_dims, self._rate_info, N, c)
+        lifted, self._vmap = epigraph.lift_cost(c, self._rate_dims, self._epi_dims, N, self._epi_blocks)
+        if not self._epi_blocks:
+            self._vmap = None
         return lifted
 
     def _ensure_problem(self):
-        blocks = self._std_obj_atoms.epigraph_blocks()
+        from . import epigraph
+        mats1, dims1, blocks, rv, info = self._augmentation()
+        N = self._N_tilde
+        if rv:
+            blocks = blocks + epigraph.rate_cost_and_blocks(self._std_obj_atoms.weights, dims1, info, N,
+                                                            dict(lin_y=np.zeros(N * dims1["ny"]), quad_y=None))
         if getattr(self, "_no_soft", False):
-            from . import epigraph
-            blocks = blocks + [epigraph.hard_block(self._model.mld_info.as_gpu_dims(), self._N_tilde)]
-        sig = self._epi_signature(blocks)
+            blocks = blocks + [epigraph.hard_block(dims1, N)]
+        sig = (tuple(rv), self._epi_signature(blocks))
         if self._problem is not None and sig != getattr(self, "_epi_sig", ()):
-            self._problem.close()                    # the set of epigraph atoms changed: another augmented model
+            self._problem.close()                    # the set of augmenting atoms changed: another augmented model
             self._problem = None
             if getattr(self, "_epi_model", None) is not None:
                 self._epi_model.close()
@@ -353,16 +380,36 @@ class MpcController(object):
             cost = self._std_obj_atoms.to_cost()
             self._omega_atoms = cost.pop("_omega_atoms", [])
             self._epi_blocks, self._epi_sig, self._vmap = blocks, sig, None
-            if blocks:
-                from . import epigraph
-                dims = self._model.mld_info.as_gpu_dims()
-                mats2, self._epi_dims, _ = epigraph.augment(self._model.as_mats(), dims, blocks)
+            self._rate_vars, self._rate_info, self._rate_dims = rv, info, dims1
+            if blocks or rv:
+                mats2, self._epi_dims, _ = epigraph.augment(mats1, dims1, blocks)
                 self._epi_model = gpu.GpuModel([mats2], self._epi_dims)
-                lifted, self._vmap = epigraph.lift_cost(cost, dims, self._epi_dims, self._N_tilde, blocks)
-                self._problem = gpu.GpuProblem(self._epi_model, self._N_p, self._N_tilde, self._signed(lifted), **self._solver_opts)
+                self._problem = gpu.GpuProblem(self._epi_model, self._N_p, self._N_tilde, self._signed(self._problem_cost(cost)), **self._solver_opts)
             else:
+                self._epi_dims = dims1
                 self._problem = gpu.GpuProblem(evo.gpu_model(), self._N_p, self._N_tilde, self._signed(cost), **self._solver_opts)
         return self._problem
+
+    def _x_problem(self, x_k=None):
+        """the state handed to the GPU problem: x_k followed by the lag states' initial values (variables_k_neg1)"""
+        x = self._x_k if x_k is None else x_k
+        if not getattr(self, "_rate_vars", None):
+            return x
+        parts = [x]
+        for v in self._rate_vars:
+            k = self._rate_info[v][2]
+            val = self._k_neg1.get(v)
+            parts.append(np.zeros((k, 1)) if val is None else atleast_2d_col(val).reshape(k, 1))
+        return np.vstack(parts)
+
+    @property
+    def variables_k_neg1(self):
+        """values at step k-1 that rate atoms ('d<var>') difference against (variables.py:88-102); missing -> zeros"""
+        return dict(self._k_neg1)
+
+    @variables_k_neg1.setter
+    def variables_k_neg1(self, struct):
+        self._k_neg1 = {k: atleast_2d_col(v) for k, v in dict(struct or {}).items() if v is not None}
 
     def _orig_rows(self, n_rows):
         """indices of the original constraint rows among the problem's rows (epigraph rows follow them in every step)"""
@@ -390,12 +437,12 @@ class MpcController(object):
         cost = self._std_obj_atoms.to_cost() if with_std_objective else {}
         self._omega_atoms = cost.pop("_omega_atoms", []) if cost else []
         self._ensure_problem()
-        has_norms = any(not b.get("one_sided") for b in self._epi_blocks)
+        has_norms = any(not b.get("one_sided") for b in self._epi_blocks) or bool(self._rate_vars)
         if has_norms and not with_std_objective:
             raise NotImplementedError("with_std_objective=False while L1 / Linf atoms are set")
         if has_norms and self._sense < 0:
             raise ValueError("L1 / Linf atoms are convex: the problem cannot be maximised")
-        cost = self._problem_cost(cost) if (cost or self._epi_blocks) else cost
+        cost = self._problem_cost(cost) if (cost or self._epi_blocks or self._rate_vars) else cost
         self._problem.set_cost(self._signed(cost) if cost else None)
         self._build_required = False
 
@@ -435,7 +482,7 @@ class MpcController(object):
                     nc = self.mld_info_k.n_constraints
                     nc_p = self._epi_dims["nc"] if self._epi_blocks else nc
                     rows = np.concatenate([np.full(b.omega_cols.shape[1], (b.rows // nc) * nc_p) for b in self._other_constraints])
-                out = self._problem.solve(self._x_k.T, self._omega_tilde_k.T, omega_cols=cols, col_rows=rows)
+                out = self._problem.solve(self._x_problem().T, self._omega_tilde_k.T, omega_cols=cols, col_rows=rows)
             except MldGpuError as e:
                 self._solve_time_solver = np.nan
                 raise ControllerSolverError(str(e)) from e

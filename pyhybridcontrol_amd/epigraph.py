@@ -12,7 +12,8 @@ system is an ordinary MLD model, so condensing, right-hand sides and the cut-and
 Atom semantics follow the reference exactly, including its quirk that ``Linf`` with a vector or matrix weight is
 evaluated as a per-step 1-norm (:355-363); the per-step max (:352-353) is only reached with no weight object at all,
 which the string-keyed atom syntax (:453-496) cannot produce.
-Rate atoms (``d<var>``) need lag states and are not covered (NotImplementedError).
+Rate atoms (``d<var>`` = var(k) - var(k-1)) become ordinary atoms on *rate outputs* of a model with lag states
+(``augment_rates``); the value before the horizon, var(k-1), is the lag states' initial condition.
 """
 import numpy as np
 
@@ -35,7 +36,7 @@ def plan(weights, dims, N):
         if atype not in ("L1", "Linf"):
             continue
         if rate:
-            raise NotImplementedError("rate ('d<var>') atoms need lag states: not on the GPU path yet")
+            continue                           # rate atoms: rate_cost_and_blocks() below
         if var not in _CON:
             raise NotImplementedError("%s atom on '%s'" % (atype, var))
         vd = dims[_VDIM[var]]
@@ -125,3 +126,127 @@ def lift_cost(cost, dims, dims2, N, blocks):
         Q[np.ix_(vmap, vmap)] = cost["quad_v"]
         out["quad_v"] = Q
     return out, vmap
+
+
+# ---- rate atoms ('d<var>': var(k) - var(k-1), objective_atoms.py:296-304) through lag states ------------------------
+_RATE_IN = dict(u=("B1", "D1", "nu"), delta=("B2", "D2", "ndelta"), z=("B3", "D3", "nz"))
+
+
+def rate_vars(weights):
+    """variables that carry a rate atom, in a fixed order"""
+    order = ("x", "u", "delta", "z", "y")
+    found = {var for (var, _a, _w, rate) in weights if rate}
+    bad = found - set(order)
+    if bad:
+        raise NotImplementedError("rate atom on %s (mu / v do not enter the state equation)" % sorted(bad))
+    return [v for v in order if v in found]
+
+
+def augment_rates(mats, dims, rvars):
+    """(mats', dims', info): lag states  x_lag(k+1) = var(k)  and rate outputs  y_d(k) = var(k) - x_lag(k)  appended to the
+    MLD system for every variable in ``rvars``.  info[var] = (lag state offset, rate output offset, dim)."""
+    nx, ny, nc = dims["nx"], dims["ny"], dims["nc"]
+    cols = dict(A="nx", B1="nu", B2="ndelta", B3="nz", B4="nomega", C="nx", D1="nu", D2="ndelta", D3="nz", D4="nomega")
+
+    def get(name, r, c):
+        a = mats.get(name)
+        if a is None or np.size(a) == 0:
+            return np.zeros((r, c))
+        return np.asarray(a, dtype=np.float64).reshape(r, c)
+
+    S = {k: get(k, nx, dims[v]) for k, v in cols.items() if k[0] in "AB"}
+    O = {k: get(k, ny, dims[v]) for k, v in cols.items() if k[0] in "CD"}
+    b5, d5 = get("b5", nx, 1), get("d5", ny, 1)
+    dim_of = dict(x=nx, y=ny, u=dims["nu"], delta=dims["ndelta"], z=dims["nz"])
+    nl = sum(dim_of[v] for v in rvars)
+    info, lo = {}, 0
+    s_rows = {k: [a] for k, a in S.items()}
+    o_rows = {k: [a] for k, a in O.items()}
+    b_rows, d_rows = [b5], [d5]
+    lagA, lagC = [], []          # (rows x nl) blocks acting on the lag states
+    for v in rvars:
+        k = dim_of[v]
+        info[v] = (nx + lo, ny + lo, k)
+        new_s = {kk: np.zeros((k, a.shape[1])) for kk, a in S.items()}
+        new_o = {kk: np.zeros((k, a.shape[1])) for kk, a in O.items()}
+        nb5, nd5 = np.zeros((k, 1)), np.zeros((k, 1))
+        if v == "x":
+            new_s["A"][:, :] = np.eye(nx); new_o["C"][:, :] = np.eye(nx)
+        elif v == "y":
+            for src, dst in (("C", "A"), ("D1", "B1"), ("D2", "B2"), ("D3", "B3"), ("D4", "B4")):
+                new_s[dst][:, :] = O[src]
+            nb5[:] = d5
+            for src in ("C", "D1", "D2", "D3", "D4"):
+                new_o[src][:, :] = O[src]
+            nd5[:] = d5
+        else:
+            bname, dname, _ = _RATE_IN[v]
+            new_s[bname][:, :] = np.eye(k); new_o[dname][:, :] = np.eye(k)
+        for kk in S:
+            s_rows[kk].append(new_s[kk])
+        for kk in O:
+            o_rows[kk].append(new_o[kk])
+        b_rows.append(nb5); d_rows.append(nd5)
+        L = np.zeros((k, nl)); L[:, lo:lo + k] = -np.eye(k)
+        lagC.append(L)
+        lo += k
+    out = {}
+    for kk in S:
+        out[kk] = np.vstack(s_rows[kk])
+    for kk in O:
+        out[kk] = np.vstack(o_rows[kk])
+    out["A"] = np.hstack([out["A"], np.zeros((nx + nl, nl))])               # lag states feed nothing but the rate outputs
+    out["C"] = np.hstack([out["C"], np.vstack([np.zeros((ny, nl))] + lagC)])
+    out["b5"], out["d5"] = np.vstack(b_rows), np.vstack(d_rows)
+    out["E"] = np.hstack([get("E", nc, nx), np.zeros((nc, nl))])
+    out["G"] = np.hstack([get("G", nc, ny), np.zeros((nc, nl))])
+    for kk in ("F1", "F2", "F3", "F4", "f5", "Psi"):
+        out[kk] = mats.get(kk)
+    d2 = dict(dims)
+    d2["nx"], d2["ny"] = nx + nl, ny + nl
+    return out, d2, info
+
+
+def lift_xy_cost(cost, dims, dims2, N):
+    """cost dict over the original x / y layouts -> the layouts with lag states / rate outputs appended per step"""
+    out = dict(cost)
+    for key, d0, d1 in (("x", dims["nx"], dims2["nx"]), ("y", dims["ny"], dims2["ny"])):
+        idx = np.concatenate([k * d1 + np.arange(d0) for k in range(N)]) if d0 else np.zeros(0, dtype=int)
+        lin = np.zeros(N * d1)
+        if cost.get("lin_" + key) is not None and d0:
+            lin[idx] = np.asarray(cost["lin_" + key], dtype=np.float64).ravel()
+        out["lin_" + key] = lin
+        if cost.get("quad_" + key) is not None:
+            Q = np.zeros((N * d1, N * d1))
+            Q[np.ix_(idx, idx)] = cost["quad_" + key]
+            out["quad_" + key] = Q
+    return out
+
+
+def rate_cost_and_blocks(weights, dims2, info, N, cost):
+    """adds the rate atoms to ``cost`` (already in the dims2 layouts) as atoms on the rate outputs; returns the epigraph
+    blocks their L1 / Linf members need"""
+    ny2 = dims2["ny"]
+    blocks = []
+    for (var, atype, wtype, rate), w in weights.items():
+        if not rate:
+            continue
+        _, yo, k = info[var]
+        rows = np.concatenate([s * ny2 + yo + np.arange(k) for s in range(N)])
+        if atype == "Linear":
+            cost["lin_y"][rows] += w[:, 0] if wtype == "vector" else w.sum(axis=0)
+        elif atype in ("Quadratic", "L22"):
+            W = np.diag(w[:, 0] ** 2) if wtype == "vector" else w
+            if cost.get("quad_y") is None:
+                cost["quad_y"] = np.zeros((N * ny2, N * ny2))
+            cost["quad_y"][np.ix_(rows, rows)] += W
+        else:                                  # L1 / Linf (= per-step 1-norm, see plan())
+            sel = np.zeros((k, ny2)); sel[:, yo:yo + k] = np.eye(k)
+            if wtype == "vector":
+                blocks.append(dict(var="y", M=sel, S=np.eye(k), cost=np.abs(w[:, 0]).reshape(N, k)))
+            else:
+                W0 = _per_step_blocks(w, k, N)
+                if W0 is None:
+                    raise NotImplementedError("%s rate atom with a matrix weight that differs between horizon steps" % atype)
+                blocks.append(dict(var="y", M=W0 @ sel, S=np.eye(k), cost=np.ones((N, k))))
+    return blocks

@@ -5,7 +5,7 @@ Only what the MPC hot path needs: parsing the string keys
 weights over the horizon (VectorWeight :76-137, MatrixWeight :140-206), dropping all-zero weights
 (:508,519-520), and turning Linear / Quadratic atoms (:308-331) into the tiled linear / quadratic
 weight arrays that libmldgpu's cost pull-back kernel (K4) consumes.  L1 / Linf atoms become epigraph rows of an
-augmented MLD model (epigraph.py); rate atoms are recognised and rejected with NotImplementedError.  This is string handling and
+augmented MLD model (epigraph.py), rate atoms ordinary atoms on rate outputs of a model with lag states.  This is string handling and
 array tiling -- no hot-path arithmetic happens here.
 """
 import re
@@ -167,8 +167,8 @@ class ObjectiveAtoms(object):
         quad = dict(v=None, x=None, y=None)
         const_omega = []
         for (var, atype, wtype, rate), w in self.weights.items():
-            if rate:
-                raise NotImplementedError("rate ('d<var>') atoms need lag states: not on the GPU path yet")
+            if rate:                         # rate atoms live on the lag-state augmentation (epigraph.augment_rates)
+                continue
             if atype in ("L1", "Linf"):      # epigraph atoms: see epigraph_blocks() / epigraph.py (a model augmentation)
                 if var == "omega":
                     raise NotImplementedError("%s atom on omega" % atype)

@@ -196,3 +196,54 @@ def test_controller_disable_soft_constraints():
         ctrl.solve(0, x_k=[49.0], omega_tilde_k=om)            # below the lower limit: only the slack made this feasible
     ctrl.build()                                                # soft again
     assert np.isfinite(ctrl.solve(0, x_k=[49.0], omega_tilde_k=om)) and ctrl.v_N_tilde.reshape(5, 3)[:, 1:].sum() > 0
+
+
+def test_controller_rate_atoms_through_lag_states():
+    """'d<var>' rate atoms (controllers/components/objective_atoms.py:296-304): switching penalty q_L1_du and a quadratic
+    rate of the state, with the value before the horizon taken from variables_k_neg1"""
+    from scipy.optimize import milp, LinearConstraint, Bounds
+    model = phc.MldModel(A=[[0.9970371127900564]], B1=[[4.298192277481107]], B4=[[-179.73320827515]],
+                         b5=[[0.07407218024859108]], E=[[1], [-1]], F1=[[0], [0]], Psi=[[-1, 0], [0, -1]],
+                         f5=[[65.0], [-50.0]], nu_l=1, ts=900)
+    ctrl = phc.MpcController(model, N_p=4)
+    price = np.array([1, 3, 3, 1, 1.0])
+    sw = 0.4
+    ctrl.set_std_obj_atoms(q_u=(price * 0.75).reshape(-1, 1), q_mu=[90.0, 90.0], q_L1_du=sw)
+    ctrl.variables_k_neg1 = {"u": [1.0]}
+    ctrl.build()
+    om = np.array([.004, .012, 0, .009, .002])
+    obj = ctrl.solve(0, x_k=[50.3], omega_tilde_k=om)
+    v = ctrl.v_N_tilde.reshape(5, 3)
+    u, mu = v[:, 0], v[:, 1:]
+    du = np.diff(np.concatenate([[1.0], u]))
+    expect = (price * 0.75) @ u + 90.0 * mu.sum() + sw * np.abs(du).sum()
+    assert np.all((u == 0) | (u == 1)) and abs(obj - expect) <= 1e-7 * max(1.0, abs(expect)), (obj, expect)
+    # explicit formulation: t_k >= +-(u_k - u_{k-1})
+    ev = cn.condense(model.as_mats(), 5)
+    cons = ctrl.gen_evo_constraints()
+    assert cons.H_v.shape == (10, 15) and np.all(cons.H_v @ ctrl.v_N_tilde <= cons.rhs + 1e-7)
+    Su = np.kron(np.eye(5), [[1.0, 0, 0]])
+    Dm = np.eye(5) - np.eye(5, k=-1)
+    off = np.array([-1.0, 0, 0, 0, 0])
+    A = np.block([[ev["H_v"], np.zeros((10, 5))], [Dm @ Su, -np.eye(5)], [-Dm @ Su, -np.eye(5)]])
+    b = np.concatenate([cons.rhs[:, 0], -off, off])
+    c = np.concatenate([np.tile([0.0, 90.0, 90.0], 5) + np.kron(price * 0.75, [1.0, 0, 0]), np.full(5, sw)])
+    lb = np.concatenate([np.zeros(15), np.full(5, -np.inf)]); ub = np.concatenate([np.tile([1.0, np.inf, np.inf], 5), np.full(5, np.inf)])
+    ref = milp(c, constraints=LinearConstraint(A, -np.inf, b), bounds=Bounds(lb, ub),
+               integrality=np.concatenate([np.tile([1, 0, 0], 5), np.zeros(5)]).astype(int))
+    assert ref.status == 0 and abs(obj - ref.fun) <= 1e-6 * max(1.0, abs(ref.fun)), (obj, ref.fun)
+    # with the heater OFF before the horizon the first switch-on costs the penalty too
+    ctrl.variables_k_neg1 = {"u": [0.0]}
+    obj0 = ctrl.solve(0, x_k=[50.3], omega_tilde_k=om)
+    u0 = ctrl.v_N_tilde.reshape(5, 3)[:, 0]
+    assert abs(obj0 - ((price * 0.75) @ u0 + 90.0 * ctrl.v_N_tilde.reshape(5, 3)[:, 1:].sum() + sw * np.abs(np.diff(np.concatenate([[0.0], u0]))).sum())) < 1e-7
+    # a quadratic rate atom on the state (MIQP path): objective equals the evaluated expression
+    ctrl.set_std_obj_atoms(q_u=(price * 0.75).reshape(-1, 1), q_mu=[90.0, 90.0], q_Quadratic_dx=0.3)
+    ctrl.variables_k_neg1 = {"x": [50.0]}
+    ctrl.build()
+    objq = ctrl.solve(0, x_k=[50.3], omega_tilde_k=om)
+    x, _ = ctrl.predicted_trajectory()
+    vq = ctrl.v_N_tilde.reshape(5, 3)
+    dx = np.diff(np.concatenate([[50.0], x[:, 0]]))
+    expq = (price * 0.75) @ vq[:, 0] + 90.0 * vq[:, 1:].sum() + (0.3 * dx) @ (0.3 * dx)
+    assert abs(objq - expq) <= 1e-6 * max(1.0, abs(expq)), (objq, expq)

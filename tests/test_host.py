@@ -73,10 +73,12 @@ def test_objective_atom_parsing_rules_and_errors():
     assert not l1.to_cost()["lin_v"][[0, 3, 6]].any()                       # the L1 atom is not a linear weight on u ...
     blocks = l1.epigraph_blocks()                                              # ... it is an epigraph block |w| t, t >= +-u
     assert len(blocks) == 1 and blocks[0]["var"] == "u" and np.array_equal(blocks[0]["cost"], 2.0 * np.ones((3, 1)))
+    rate = phc.ObjectiveAtoms(dims, 2, 3, {"q_du": 1.0, "q_L1_du": 2.0})     # rate atoms: not in the plain cost, not plain epigraph blocks
+    assert not rate.to_cost()["lin_v"].any() and rate.epigraph_blocks() == []
+    from pyhybridcontrol_amd import epigraph
+    assert epigraph.rate_vars(rate.weights) == ["u"]
     with pytest.raises(NotImplementedError):
-        phc.ObjectiveAtoms(dims, 2, 3, {"q_du": 1.0}).to_cost()
-    with pytest.raises(NotImplementedError):
-        phc.ObjectiveAtoms(dims, 2, 3, {"q_L1_du": 1.0}).epigraph_blocks()
+        epigraph.rate_vars(phc.ObjectiveAtoms(dims, 2, 3, {"q_dmu": [1.0, 1.0]}).weights)
     q22 = phc.ObjectiveAtoms(dims, 2, 3, {"q_L22_x": 3.0}).to_cost()           # L22 is the quadratic atom
     assert np.array_equal(q22["quad_x"], 9.0 * np.eye(3))
     assert not phc.ObjectiveAtoms(dims, 2, 3, {"q_u": 0.0}).weights           # all-zero weights are dropped
@@ -239,3 +241,68 @@ def test_epigraph_augmentation_equals_explicit_norm_formulation():
     xs = ev["Gamma_v"] @ v + xaff
     norm_cost = np.abs(w_u[:, 0] * (Su @ v)).sum() + np.abs(Wx @ xs).sum()
     assert abs(np.asarray(cost["lin_v"]).ravel() @ v + norm_cost - r2.fun) <= 1e-7 * max(1.0, abs(r2.fun))
+
+
+def test_rate_augmentation_equals_explicit_difference_formulation():
+    """epigraph.augment_rates: lag states + rate outputs turn  sum_k w_k |u_k - u_{k-1}| + sum_k q (z_k - z_{k-1})^2-type
+    atoms into ordinary atoms; checked with HiGHS (MILP, L1 + linear rate atoms) against the problem written with
+    explicit difference variables on the ORIGINAL condensed matrices, including the value before the horizon."""
+    from scipy.optimize import milp, LinearConstraint, Bounds
+    from pyhybridcontrol_amd import epigraph
+    wl = syn.make_workload("cfg2", batch=1)
+    ag = wl["agents"][0]
+    d, N_p, N = ag["dims"], 5, 6
+    rng = np.random.default_rng(21)
+    nu = d["nu"]
+    w_du = rng.uniform(0.05, 0.2, size=(N * nu, 1))
+    q_dx = rng.normal(size=(d["nx"], 1)) * 1e-3
+    atoms = {"q_z": rng.uniform(0.01, 0.1, size=(N * d["nz"], 1)), "q_mu": np.full((d["nmu"], 1), 5.0),
+             "q_L1_du": w_du, "q_dx": q_dx}
+    oa = phc.ObjectiveAtoms(d, N_p, N, atoms)
+    rv = epigraph.rate_vars(oa.weights)
+    assert rv == ["x", "u"]
+    mats1, d1, info = epigraph.augment_rates(ag["mats"], d, rv)
+    assert d1["nx"] == d["nx"] + d["nx"] + nu and d1["ny"] == d["ny"] + d["nx"] + nu
+    cost = oa.to_cost(); cost.pop("_omega_atoms")
+    c1 = epigraph.lift_xy_cost(cost, d, d1, N)
+    blocks = epigraph.rate_cost_and_blocks(oa.weights, d1, info, N, c1)
+    assert len(blocks) == 1 and blocks[0]["var"] == "y"
+    mats2, d2, nt = epigraph.augment(mats1, d1, blocks)
+    lifted, vmap = epigraph.lift_cost(c1, d1, d2, N, blocks)
+    x0, om = ag["x0"][0], ag["omega"][0][:N * d["nomega"]]
+    u_prev, x_prev = np.array([1.0, 0.0, 1.0]), x0 + 0.7
+    x_ext = np.concatenate([x0, x_prev, u_prev])                   # lag states in rate_vars order: x then u
+    # (1) augmented model through the numpy restatement
+    ev2 = cn.condense(mats2, N)
+    nv2 = d2["nu"] + d2["ndelta"] + d2["nz"] + d2["nmu"]
+    h2 = ev2["H_x"] @ x_ext + ev2["H_omega"] @ om + ev2["H_5"][:, 0]
+    yaff = ev2["L_x"] @ x_ext + ev2["L_omega"] @ om + ev2["L_5"][:, 0]
+    q2 = lifted["lin_v"] + ev2["L_v"].T @ lifted["lin_y"]
+    const2 = lifted["lin_y"] @ yaff
+    lb2, ub2, bin2 = np.full(N * nv2, -np.inf), np.full(N * nv2, np.inf), np.zeros(N * nv2, bool)
+    for k in range(N):
+        o = k * nv2
+        lb2[o:o + nu + d["ndelta"]] = 0; ub2[o:o + nu + d["ndelta"]] = 1; bin2[o:o + nu + d["ndelta"]] = True
+        lb2[o + nv2 - d["nmu"]:o + nv2] = 0
+    r2 = milp(q2, constraints=LinearConstraint(ev2["H_v"], -np.inf, h2), bounds=Bounds(lb2, ub2), integrality=bin2.astype(int))
+    # (2) written down directly on the original matrices: t >= +-(u_k - u_{k-1}),  q'(x_k - x_{k-1}) telescopes per step
+    ev = cn.condense(ag["mats"], N)
+    nv, n = d["nu"] + d["ndelta"] + d["nz"] + d["nmu"], N * (d["nu"] + d["ndelta"] + d["nz"] + d["nmu"])
+    Su = np.zeros((N * nu, n))
+    for k in range(N):
+        Su[k * nu:(k + 1) * nu, k * nv:k * nv + nu] = np.eye(nu)
+    Dm = np.eye(N * nu) - np.kron(np.eye(N, k=-1), np.eye(nu))      # u_k - u_{k-1}
+    off = np.zeros(N * nu); off[:nu] = -u_prev
+    xaff = ev["Phi_x"] @ x0 + ev["Gamma_omega"] @ om + ev["Gamma_5"][:, 0]
+    Dx = np.eye(N * d["nx"]) - np.kron(np.eye(N, k=-1), np.eye(d["nx"]))
+    offx = np.zeros(N * d["nx"]); offx[:d["nx"]] = -x_prev
+    qx = np.tile(q_dx[:, 0], N)
+    A = np.block([[ev["H_v"], np.zeros((ev["H_v"].shape[0], N * nu))], [Dm @ Su, -np.eye(N * nu)], [-Dm @ Su, -np.eye(N * nu)]])
+    b = np.concatenate([ev["H_x"] @ x0 + ev["H_omega"] @ om + ev["H_5"][:, 0], -off, off])
+    c = np.concatenate([np.asarray(cost["lin_v"]).ravel() + (qx @ Dx) @ ev["Gamma_v"], w_du[:, 0]])
+    const1 = qx @ (Dx @ xaff + offx)
+    lb = np.concatenate([lb2[vmap], np.full(N * nu, -np.inf)]); ub = np.concatenate([ub2[vmap], np.full(N * nu, np.inf)])
+    isb = np.concatenate([bin2[vmap], np.zeros(N * nu, bool)])
+    r1 = milp(c, constraints=LinearConstraint(A, -np.inf, b), bounds=Bounds(lb, ub), integrality=isb.astype(int))
+    assert r1.status == 0 and r2.status == 0
+    assert abs((r1.fun + const1) - (r2.fun + const2)) <= 1e-7 * max(1.0, abs(r1.fun + const1)), (r1.fun + const1, r2.fun + const2)
