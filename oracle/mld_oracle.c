@@ -48,6 +48,7 @@ typedef struct {
 typedef struct {
     double gap_abs, gap_rel;
     int max_nodes, cut_rounds, cuts_per_round, max_cuts, max_pivots, presolve;
+    int mir_per_round;   /* c-MIR cuts on the original rows per cut round (0 = off) */
 } orc_opts;
 
 typedef struct {
@@ -856,6 +857,121 @@ static int gmi_round(dict_t *t, int max_cuts)
     return added;
 }
 
+/* Complemented mixed-integer rounding (Marchand & Wolsey 2001) on the ORIGINAL rows  g.x <= h  (scaled space).  The tank
+ * rows of an MLD-MPC problem are knapsack rows over the horizon's binaries with one continuous slack (lot-sizing
+ * structure): rounding them gives what a single Gomory cut of the current vertex cannot.  Binaries above 1/2 are
+ * complemented, continuous variables are bound-substituted, the row is divided by delta in {|g_j| of fractional binaries}
+ * x {1, 1/2, 1/4, 1/8} and the MIR inequality with the best efficacy is kept.  Up to max_cuts rows are appended. */
+typedef struct { double eff; int row; double delta; } mir_cand_t;
+static int mir_cmp(const void *a, const void *b) { const double x = ((const mir_cand_t *)a)->eff, y = ((const mir_cand_t *)b)->eff; return x > y ? -1 : (x < y ? 1 : ((const mir_cand_t *)a)->row - ((const mir_cand_t *)b)->row); }
+
+/* builds the cut for (row, delta) into ax/bx (structural, "ax.x <= bx"); returns the violation at x (<= 0: no cut) */
+static double mir_build(const dict_t *t, int i, double delta, const double *x, double *ax, double *bx_out, double *nrm2_out)
+{
+    const int n = t->n;
+    const double *g = t->Gx + (size_t)i * n;
+    double rhs = t->hx[i], sval = 0.0;
+    for (int j = 0; j < n; ++j) ax[j] = 0.0;
+    /* pass 1: right-hand side after complementing / bound substitution */
+    for (int j = 0; j < n; ++j) {
+        const double gj = g[j];
+        if (gj == 0.0) continue;
+        const double lo = t->lo[j], hi = t->hi[j];
+        if (t->is_int[j]) { if (lo == hi) rhs -= gj * lo; else if (x[j] > 0.5) rhs -= gj; }
+        else {
+            const int lof = lo > -0.5 * ORC_BIG, hif = hi < 0.5 * ORC_BIG;
+            if (gj > 0) { if (lof) rhs -= gj * lo; else if (hif) { rhs -= gj * hi; sval += gj * (hi - x[j]); } else return -1.0; }
+            else { if (lof) { rhs -= gj * lo; sval += -gj * (x[j] - lo); } else if (hif) rhs -= gj * hi; else return -1.0; }
+        }
+    }
+    const double b = rhs / delta, fb = floor(b), f = b - fb;
+    if (f < 0.05 || f > 0.95) return -1.0;
+    double lhs = 0.0, nrm2 = 0.0, bx = fb;
+    const double kc = 1.0 / (delta * (1.0 - f));
+    for (int j = 0; j < n; ++j) {
+        const double gj = g[j];
+        if (gj == 0.0) continue;
+        const double lo = t->lo[j], hi = t->hi[j];
+        if (t->is_int[j]) {
+            if (lo == hi) continue;
+            const int comp = x[j] > 0.5;
+            const double a = (comp ? -gj : gj) / delta, fl = floor(a + 1e-12), fj = a - fl;
+            const double cf = fl + (fj > f ? (fj - f) / (1.0 - f) : 0.0);
+            lhs += cf * (comp ? 1.0 - x[j] : x[j]);
+            if (comp) { ax[j] -= cf; bx -= cf; } else ax[j] += cf;
+        } else {
+            const int lof = lo > -0.5 * ORC_BIG, hif = hi < 0.5 * ORC_BIG;
+            if (gj > 0) { if (!lof && hif) { ax[j] += kc * gj; bx += kc * gj * hi; } }          /* x = hi - x', coefficient -g on x' */
+            else { if (lof) { ax[j] -= kc * (-gj); bx -= kc * (-gj) * lo; } }                   /* x = lo + x', coefficient g on x' */
+        }
+    }
+    lhs -= sval * kc;
+    for (int j = 0; j < n; ++j) nrm2 += ax[j] * ax[j];
+    *bx_out = bx; *nrm2_out = nrm2;
+    return lhs - fb;
+}
+
+static int mir_round(dict_t *t, int max_cuts)
+{
+    const int n = t->n, ld = t->ld, m = t->m, m0 = t->m0;
+    double *x = dalloc(n), *ax = dalloc(n);
+    for (int c = 0; c < n; ++c) if (t->nonbasic[c] < n) x[t->nonbasic[c]] = t->xN[c];
+    for (int r = 0; r < m; ++r) if (t->basic[r] < n) x[t->basic[r]] = t->xB[r];
+    mir_cand_t *cand = (mir_cand_t *)calloc(m0 + 1, sizeof(mir_cand_t));
+    int nc = 0;
+    static const double divs[4] = {1.0, 2.0, 4.0, 8.0};
+    for (int i = 0; i < m0; ++i) {
+        const double *g = t->Gx + (size_t)i * n;
+        double best = 0.0, bdelta = 0.0;
+        for (int j = 0; j < n; ++j) {
+            if (g[j] == 0.0 || !t->is_int[j] || t->lo[j] == t->hi[j]) continue;
+            if (x[j] < 1e-6 || x[j] > 1 - 1e-6) continue;
+            for (int q = 0; q < 4; ++q) {
+                const double delta = fabs(g[j]) / divs[q];
+                if (delta < 1e-9) continue;
+                double bx, nrm2;
+                const double viol = mir_build(t, i, delta, x, ax, &bx, &nrm2);
+                if (viol <= 1e-6 || nrm2 <= 0) continue;
+                const double eff = viol / sqrt(nrm2);
+                if (eff > best) { best = eff; bdelta = delta; }
+            }
+        }
+        if (best > 1e-4) { cand[nc].eff = best; cand[nc].row = i; cand[nc].delta = bdelta; nc++; }
+    }
+    qsort(cand, nc, sizeof(mir_cand_t), mir_cmp);
+    int added = 0;
+    const int m_start = m;
+    for (int q = 0; q < nc; ++q) {
+        if (m_start + added >= t->mcap || added >= max_cuts) break;
+        double bx, nrm2;
+        if (mir_build(t, cand[q].row, cand[q].delta, x, ax, &bx, &nrm2) <= 1e-6) continue;
+        double nrm = 0;
+        for (int j = 0; j < n; ++j) if (fabs(ax[j]) > nrm) nrm = fabs(ax[j]);
+        if (nrm <= 0) continue;
+        const int k = m_start + added;
+        double *gk = t->Gx + (size_t)k * n, *dk = t->D + (size_t)k * ld;
+        for (int j = 0; j < n; ++j) gk[j] = ax[j] / nrm;
+        t->hx[k] = bx / nrm;
+        /* dictionary row of the new slack: s = hx - gk.x with the basic structurals substituted */
+        for (int c = 0; c <= n; ++c) dk[c] = 0.0;
+        dk[n] = t->hx[k];
+        for (int c = 0; c < n; ++c) { const int j = t->nonbasic[c]; if (j < n) dk[c] += gk[j]; }
+        for (int r = 0; r < m; ++r) {
+            const int j = t->basic[r];
+            if (j >= n || gk[j] == 0.0) continue;
+            const double *dr = t->D + (size_t)r * ld;
+            for (int c = 0; c < n; ++c) dk[c] -= gk[j] * dr[c];
+            dk[n] -= gk[j] * dr[n];
+        }
+        t->basic[k] = n + k; t->where[n + k] = -1 - k;
+        added++;
+    }
+    t->m = m_start + added;
+    if (added) refresh(t);
+    free(x); free(ax); free(cand);
+    return added;
+}
+
 static double gtol(const orc_opts *o, double v) { return fmax(o->gap_abs, o->gap_rel * fabs(v)); }
 
 int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double *G, const double *h, const double *lb_in,
@@ -945,7 +1061,8 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
             const long saved_cap = t->max_pivots;
             for (int rnd = 0; rnd < o->cut_rounds; ++rnd) {
                 const double before = objective(t);
-                const int k = gmi_round(t, o->cuts_per_round);
+                int k = gmi_round(t, o->cuts_per_round);
+                if (o->mir_per_round > 0) k += mir_round(t, o->mir_per_round);
                 if (!k) break;
                 st->cuts += k;
                 const long cap = t->pivots + 4L * m + 200;

@@ -22,7 +22,8 @@ class Dims(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("gap_abs", C.c_double), ("gap_rel", C.c_double), ("max_nodes", C.c_int), ("cut_rounds", C.c_int),
-                ("cuts_per_round", C.c_int), ("max_cuts", C.c_int), ("max_pivots", C.c_int), ("presolve", C.c_int)]
+                ("cuts_per_round", C.c_int), ("max_cuts", C.c_int), ("max_pivots", C.c_int), ("presolve", C.c_int),
+                ("mir_per_round", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -56,8 +57,8 @@ def _p(a):
 
 
 def make_opts(gap_abs=1e-9, gap_rel=0.0, max_nodes=100000, cut_rounds=8, cuts_per_round=40, max_cuts=200,
-              max_pivots=0, presolve=1):
-    return Opts(gap_abs, gap_rel, max_nodes, cut_rounds, cuts_per_round, max_cuts, max_pivots, presolve)
+              max_pivots=0, presolve=1, mir_per_round=20):
+    return Opts(gap_abs, gap_rel, max_nodes, cut_rounds, cuts_per_round, max_cuts, max_pivots, presolve, mir_per_round)
 
 
 def solve_milp(q, G, h, lb, ub, is_bin, **kw):
