@@ -30,7 +30,8 @@ class Dims(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("gap_abs", C.c_double), ("gap_rel", C.c_double), ("max_nodes", C.c_int32),
                 ("max_pivots", C.c_int32), ("cut_rounds", C.c_int32), ("cuts_per_round", C.c_int32),
-                ("max_cuts", C.c_int32), ("presolve", C.c_int32), ("n_slots", C.c_int32), ("reserved", C.c_int32)]
+                ("max_cuts", C.c_int32), ("presolve", C.c_int32), ("n_slots", C.c_int32), ("mir_per_round", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class Cost(C.Structure):
