@@ -7,7 +7,7 @@ nodes = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 wl = syn.make_workload("cfg5", batch=B)
 ag = wl["agents"][0]; d = ag["dims"]
 m = gpu.GpuModel([ag["mats"]], d)
-p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"]), gap_rel=1e-2, max_nodes=nodes, max_pivots=20000)
+p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"]), gap_rel=1e-2, max_nodes=nodes, max_pivots=20000, **(eval('dict(%s)' % sys.argv[3]) if len(sys.argv) > 3 else {}))
 p.upload(ag["x0"], ag["omega"]); st = p.solve_resident(); out = p.download(); tel = p.telemetry()
 print({k: st[k] for k in ("solve_ms", "pivots", "nodes", "n_optimal", "n_infeasible", "n_node_limit", "n_numerical")})
 secs = tel["rows_updated"].sum()
