@@ -229,7 +229,7 @@ def main():
         result["roofline_condense"] = {"kernel": "k_condense_blocks+k_condense_flat", "bound": "hbm", "achieved": round(ach, 1),
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                        "bytes_per_model": int(bytes_cond), "models": args.agents, "kernel_ms": round(ms, 4)}
-        if not args.no_cpu and args.cpu_sample > 0:
+        if world == 1 and not args.no_cpu and args.cpu_sample > 0:    # CPU leg: rank 0 at N=1 only
             result["cpu_baseline"] = cpu_baseline(agents, N_p, N_t, x0, om, midx, args.cpu_sample, args.mip_gap, args.node_limit, args.pivot_limit)
         else:
             result["cpu_baseline"] = None
