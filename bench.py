@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--pivot-limit", type=int, default=20000, help="per-instance simplex iteration limit")
     ap.add_argument("--cpu-sample", type=int, default=24, help="instances timed with the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--rehearse", action="store_true", help="multi-rank rehearsal on ONE GPU: gloo instead of RCCL, every rank on device 0")
     return ap.parse_args()
 
 
@@ -130,10 +131,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        if args.rehearse:
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world)
     from pyhybridcontrol_amd import _lib, gpu, host
-    from pyhybridcontrol_amd.batch import RcclGather
+    from pyhybridcontrol_amd.batch import RcclGather, TorchGather
     _lib.check(_lib.load().mld_set_device(local_rank))
     agents, N_p, N_t, x0, om, midx = make_shard(args.agents, args.scenarios, rank * args.scenarios)
     d = agents[0]["dims"]
@@ -144,15 +149,19 @@ def main():
     prob.upload(x0, om, midx)                       # inputs resident in HBM before the timed region
     gatherer = None
     if world > 1:
-        ids = [RcclGather.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        gatherer = RcclGather(world, rank, ids[0])
+        if args.rehearse:
+            gatherer = TorchGather(dist)
+        else:
+            ids = [RcclGather.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            gatherer = RcclGather(world, rank, ids[0])
 
     def sync():
         if world > 1:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if not args.rehearse:
+                torch.cuda.synchronize()
 
     def step():
         st = prob.solve_resident()                  # K3 + K5/K6 on resident inputs, HIP-event timed inside
@@ -170,7 +179,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # ---- roofline of the dominant kernel (k_solve): bytes the rank-1 dictionary updates streamed / HIP-event time
