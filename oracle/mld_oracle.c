@@ -14,8 +14,12 @@
  *       Gurobi is third-party, proprietary, un-pinned and absent from /root/reference; what is
  *       restated here is the published textbook algorithm: bounded dual simplex on a dense
  *       dictionary with a Harris ratio test (Chvatal 1983; Harris 1973), Gomory mixed-integer cut
- *       rounds at the root (Gomory 1960; Balas/Ceria/Cornuejols/Natraj 1996), row-activity bound
- *       propagation (Savelsbergh 1994) and depth-first LP-based branch-and-bound (Land/Doig 1960).
+ *       rounds at the root (Gomory 1960; Balas/Ceria/Cornuejols/Natraj 1996) together with complemented
+ *       mixed-integer rounding cuts on the original rows (Marchand/Wolsey 2001), row-activity bound
+ *       propagation (Savelsbergh 1994), depth-first LP-based branch-and-bound (Land/Doig 1960) with
+ *       iterative deepening on the bound (Korf 1985), a look-ahead dive + RINS (Danna/Rothberg/Le Pape
+ *       2005) for degenerate instances, reduced-cost fixing, and convex-QP node relaxations by
+ *       simplicial decomposition (von Hohenbalken 1977).
  *
  * Pinning: (1),(2) against golden vectors produced by the reference itself (tests/golden/, made by
  * oracle/gen_golden.py); (3) has no reference fixture (the reference has no tests) -> "parity
