@@ -62,7 +62,7 @@ typedef struct {
     int32_t cuts_per_round;/* default 40 */
     int32_t max_cuts;      /* rows reserved for cuts (default 200) */
     int32_t presolve;      /* bit1: per-model probing-based big-M tightening (default 2); bit0 reserved */
-    int32_t n_slots;       /* resident workgroups (0 = auto: 2 per CU) */
+    int32_t n_slots;       /* solver slots = persistent workgroups (0 = auto: what is resident at once, one per CU) */
     int32_t mir_per_round; /* complemented mixed-integer rounding cuts on the original rows per cut round (default 20, 0 = off) */
     int32_t reserved;
 } mld_opts;
