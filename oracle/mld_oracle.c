@@ -424,6 +424,24 @@ static void refactor(dict_t *t)
         if (j < n && want[j]) place(t, c);   /* could not be pivoted in (numerically singular basis): park at a bound */
         else { t->xN[c] = val[j]; t->at_upper[c] = up[j]; }
     }
+    /* If a wanted variable could not be pivoted in, the basis is another one and reduced costs may have the wrong sign:
+     * boxed columns move to the matching bound; a slack (or free) column cannot -- then the dictionary is restarted from
+     * the slack basis with every column at its dual-feasible bound (the dual simplex re-solves from there). */
+    {
+        const double *dd = t->D + (size_t)t->mcap * ld;
+        int bad = 0;
+        for (int c = 0; c < n; ++c) {
+            const int j = t->nonbasic[c];
+            if (t->lo[j] == t->hi[j]) continue;
+            const double viol = t->at_upper[c] ? dd[c] : -dd[c];
+            if (viol <= 1e-7) continue;
+            if (j < n) place(t, c); else bad = 1;
+        }
+        if (bad) {
+            reset_dictionary(t);
+            for (int c = 0; c < n; ++c) place(t, c);
+        }
+    }
     refresh(t);
     free(want); free(rowfree); free(val); free(up);
 }
@@ -436,8 +454,13 @@ static int dual_simplex(dict_t *t, double cutoff)
     int stall = 0;
     double last_obj = -INFINITY;
     const double *d = t->D + (size_t)t->mcap * ld;
+    long checked_at = t->pivots;     /* pivot count at the last verification against the original rows */
     for (;;) {
         if (t->pivots >= t->max_pivots) return LP_ITERLIMIT;
+        if (t->pivots - checked_at >= 512) {   /* a long solve never reaches the verification at an optimum: verify on the way */
+            checked_at = t->pivots;
+            if (check_residual(t) > ORC_RESID_TOL) { refactor(t); memset(t->skip, 0, (size_t)t->mcap); continue; }
+        }
         const double cur = objective(t);
         if (cur > last_obj + 1e-12 * fmax(1.0, fabs(cur))) { stall = 0; last_obj = cur; } else stall++;
         const int bland = stall > 30;
@@ -450,6 +473,7 @@ static int dual_simplex(dict_t *t, double cutoff)
             if (v > ORC_PTOL && j < rb_id) { rb_id = j; rb = i; }
         }
         if (r < 0) {
+            checked_at = t->pivots;
             if (check_residual(t) > ORC_RESID_TOL) { refactor(t); memset(t->skip, 0, (size_t)t->mcap); continue; }
             return LP_OPTIMAL;
         }
@@ -488,6 +512,12 @@ static int dual_simplex(dict_t *t, double cutoff)
         }
         if (!any) {
             if (viol <= ORC_PTOL_SKIP) { t->skip[r] = 1; continue; }
+            if (t->pivots > checked_at) {
+                /* a violated row without an eligible entry may be accumulated error (a degenerate basic variable drifting
+                 * off its bound): verify against the original rows before believing it */
+                checked_at = t->pivots;
+                if (check_residual(t) > 0.1 * ORC_RESID_TOL) { refactor(t); memset(t->skip, 0, (size_t)t->mcap); continue; }
+            }
             return LP_INFEASIBLE;
         }
         int cbest = -1; double abest = -1; int idbest = 0x7fffffff;

@@ -15,7 +15,7 @@ print("n", p.n, "sectors updated", secs, "bytes %.3e" % (secs * 128.0), "GB/s %.
       "pivots/s %.0f" % (st["pivots"] / st["solve_ms"] * 1e3), "solves/s %.1f" % (B / st["solve_ms"] * 1e3))
 lim = out["status"] == 2
 fin = np.isfinite(out["obj"])
-print("no incumbent", int((~fin).sum()), "numerical idx", np.where(out["status"] == 3)[0][:5])
+print("no incumbent", int((~fin).sum()), "numerical idx", np.where(out["status"] == 3)[0][:5], "infeasible idx", np.where(out["status"] == 1)[0][:8])
 if (lim & fin).any():
     g = (out["obj"][lim & fin] - out["lower_bound"][lim & fin]) / np.abs(out["obj"][lim & fin])
     print("gap of limited: median %.4f p90 %.4f max %.4f" % (np.median(g), np.percentile(g, 90), g.max()))
