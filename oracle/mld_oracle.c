@@ -512,11 +512,12 @@ static int dual_simplex(dict_t *t, double cutoff)
         }
         if (!any) {
             if (viol <= ORC_PTOL_SKIP) { t->skip[r] = 1; continue; }
-            if (t->pivots > checked_at) {
-                /* a violated row without an eligible entry may be accumulated error (a degenerate basic variable drifting
-                 * off its bound): verify against the original rows before believing it */
+            if (t->pivots > checked_at && viol <= 1e-3) {
+                /* a SMALL violation without an eligible entry may be accumulated error (a degenerate basic variable
+                 * drifting off its bound) rather than infeasibility: if the dictionary's discrepancy against the original
+                 * rows is of the violation's size, re-derive it before believing the row */
                 checked_at = t->pivots;
-                if (check_residual(t) > 0.1 * ORC_RESID_TOL) { refactor(t); memset(t->skip, 0, (size_t)t->mcap); continue; }
+                if (check_residual(t) > 0.1 * viol) { refactor(t); memset(t->skip, 0, (size_t)t->mcap); continue; }
             }
             return LP_INFEASIBLE;
         }
