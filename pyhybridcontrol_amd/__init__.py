@@ -11,3 +11,4 @@ from .controllers import (MpcController, MldEvoMatrices, ControllerBuildRequired
 from .gpu import GpuModel, GpuProblem  # noqa: F401
 from .batch import BatchSolver, shard_range, gather_sharded  # noqa: F401
 from .aux_resolve import AuxResolver  # noqa: F401
+from .compose import fuse  # noqa: F401

@@ -247,3 +247,37 @@ def test_controller_rate_atoms_through_lag_states():
     dx = np.diff(np.concatenate([[50.0], x[:, 0]]))
     expq = (price * 0.75) @ vq[:, 0] + 90.0 * vq[:, 1:].sum() + (0.3 * dx) @ (0.3 * dx)
     assert abs(objq - expq) <= 1e-6 * max(1.0, abs(expq)), (objq, expq)
+
+
+def test_fused_grid_of_two_heaters_solves_like_the_oracle():
+    """compose.fuse (the numeric counterpart of micro_grid_agents.py:625-709): two DEWH devices and a grid tie that prices
+    max(0, total power) become ONE MLD problem; GPU objective == oracle objective on the fused standard form, and the
+    fused optimum is at least the sum of the two devices' stand-alone optima (import is priced on the total)."""
+    P = 3000.0
+    dewh = lambda a, b: (dict(A=[[a]], B1=[[b]], B4=[[-179.73320827515]], b5=[[0.07407218024859108]], C=[[0.0]], D1=[[P]],
+                              E=[[1], [-1]], F1=[[0], [0]], Psi=[[-1, 0], [0, -1]], f5=[[65.0], [-50.0]]),
+                         dict(nx=1, nu=1, ndelta=0, nz=0, nmu=2, nomega=1, ny=1, nc=2, nu_l=1, nmu_l=0))
+    devs = [dewh(0.9970371127900564, 4.298192277481107), dewh(0.9965, 3.9)]
+    # grid: y_g = P_1 + P_2 + load ; z >= y_g, z >= 0 (import energy priced by q_z); no state
+    grid = (dict(C=np.zeros((1, 0)), D4=[[1.0, 1.0, 1.0]], E=np.zeros((2, 0)), F3=[[-1.0], [-1.0]], F4=np.zeros((2, 3)),
+                 G=[[1.0], [0.0]], f5=[[0.0], [0.0]]),
+            dict(nx=0, nu=0, ndelta=0, nz=1, nmu=0, nomega=3, ny=1, nc=2, nu_l=0, nmu_l=0))
+    mats, dims, lay = phc.fuse(devs, grid)
+    assert dims["nu"] == 2 and dims["nu_l"] == 2 and dims["nz"] == 1 and dims["nomega"] == 3 and dims["nc"] == 6
+    N_p, N = 5, 6
+    price = np.array([1, 3, 3, 1, 1, 2.0]) * 1e-3
+    atoms = {"q_z": price.reshape(-1, 1), "q_mu": np.full((4, 1), 90.0)}
+    m = gpu.GpuModel([mats], dims)
+    p = gpu.GpuProblem(m, N_p, N, host.cost_from_atoms(atoms, dims, N_p, N), max_nodes=20000)
+    x0 = np.array([[50.3, 51.0]])
+    om = np.tile([0.004, 0.006, -1500.0], N)[None]            # draws of the two tanks, net load (PV surplus of 1.5 kW)
+    out = p.solve(x0, om)
+    sf = cn.standard_form(tighten_np.tighten(mats, dims, nu_l=dims["nu_l"]), atoms, N_p, N, nu_l=dims["nu_l"])
+    ref = orc.solve_milp(cn.lin_cost(sf["cost"], x0[0], om[0]), sf["G"], cn.rhs(sf["evo"], x0[0], om[0]), sf["lb"], sf["ub"], sf["is_bin"],
+                         max_nodes=20000, presolve=0)
+    r0 = cn.cost_const(sf["cost"]["const_terms"], x0[0], om[0])
+    assert out["status"][0] == 0 and ref["status"] == "optimal"
+    assert abs(out["obj"][0] - (ref["obj"] + r0)) <= 1e-6 * max(1.0, abs(ref["obj"] + r0)), (out["obj"][0], ref["obj"] + r0)
+    v = out["v"][0].reshape(N, -1)
+    assert np.all((v[:, :2] == 0) | (v[:, :2] == 1))
+    p.close(); m.close()

@@ -306,3 +306,50 @@ def test_rate_augmentation_equals_explicit_difference_formulation():
     r1 = milp(c, constraints=LinearConstraint(A, -np.inf, b), bounds=Bounds(lb, ub), integrality=isb.astype(int))
     assert r1.status == 0 and r2.status == 0
     assert abs((r1.fun + const1) - (r2.fun + const2)) <= 1e-7 * max(1.0, abs(r1.fun + const1)), (r1.fun + const1, r2.fun + const2)
+
+
+def test_fused_grid_model_equals_sequential_evaluation():
+    """compose.fuse: devices + grid as ONE MLD system (the numeric counterpart of the example's cvxpy-level composition,
+    micro_grid_agents.py:625-709): state update, outputs and constraint residuals of the fused system equal evaluating
+    the devices first and feeding their outputs into the grid's disturbance channel"""
+    from pyhybridcontrol_amd import compose
+    rng = np.random.default_rng(8)
+
+    def rand_model(nx, nu, nd, nz, nmu, nw, ny, nc, nu_l):
+        d = dict(nx=nx, nu=nu, ndelta=nd, nz=nz, nmu=nmu, nomega=nw, ny=ny, nc=nc, nu_l=nu_l, nmu_l=0)
+        shp = dict(A=(nx, nx), B1=(nx, nu), B2=(nx, nd), B3=(nx, nz), B4=(nx, nw), b5=(nx, 1), C=(ny, nx), D1=(ny, nu), D2=(ny, nd),
+                   D3=(ny, nz), D4=(ny, nw), d5=(ny, 1), E=(nc, nx), F1=(nc, nu), F2=(nc, nd), F3=(nc, nz), F4=(nc, nw), f5=(nc, 1),
+                   G=(nc, ny), Psi=(nc, nmu))
+        return {k: rng.normal(size=v) for k, v in shp.items()}, d
+
+    devs = [rand_model(2, 1, 1, 1, 2, 1, 1, 4, 1), rand_model(1, 2, 0, 1, 1, 2, 1, 3, 2), rand_model(1, 1, 0, 0, 0, 1, 2, 2, 0)]
+    grid = rand_model(1, 0, 1, 1, 1, 5, 1, 4, 0)            # 4 device outputs + 1 external disturbance
+    mats, dims, lay = compose.fuse(devs, grid)
+    assert dims["nx"] == 5 and dims["nu"] == 4 and dims["nu_l"] == 3 and dims["nomega"] == 1 + 2 + 1 + 1 and dims["ny"] == 5
+    assert lay["u"][2] == (0, 1)                              # the continuous-input device comes first: binaries stay trailing
+
+    def ev(m, d, x, u, dl, z, mu, w):
+        y = m["C"] @ x + m["D1"] @ u + m["D2"] @ dl + m["D3"] @ z + m["D4"] @ w + m["d5"][:, 0]
+        x1 = m["A"] @ x + m["B1"] @ u + m["B2"] @ dl + m["B3"] @ z + m["B4"] @ w + m["b5"][:, 0]
+        r = m["E"] @ x + m["F1"] @ u + m["F2"] @ dl + m["F3"] @ z + m["F4"] @ w + m["G"] @ y + m["Psi"] @ mu - m["f5"][:, 0]
+        return x1, y, r
+    subs = devs + [grid]
+    vals = [{v: rng.normal(size=d[k]) for v, k in (("x", "nx"), ("u", "nu"), ("delta", "ndelta"), ("z", "nz"), ("mu", "nmu"), ("omega", "nomega"))}
+            for _, d in subs]
+    outs = [ev(m, d, *(vals[i][v] for v in ("x", "u", "delta", "z", "mu", "omega"))) for i, (m, d) in enumerate(devs)]
+    wg = np.concatenate([o[1] for o in outs] + [vals[3]["omega"][4:]])
+    outs.append(ev(grid[0], grid[1], vals[3]["x"], vals[3]["u"], vals[3]["delta"], vals[3]["z"], vals[3]["mu"], wg))
+    stack = {}
+    for v, key in (("x", "nx"), ("u", "nu"), ("delta", "ndelta"), ("z", "nz"), ("mu", "nmu"), ("omega", "nomega")):
+        a = np.zeros(dims[key])
+        for i in range(4):
+            o, k = lay[v][i]
+            a[o:o + k] = vals[i][v][4:] if (v == "omega" and i == 3) else vals[i][v]
+        stack[v] = a
+    X1, Y, R = ev(mats, dims, stack["x"], stack["u"], stack["delta"], stack["z"], stack["mu"], stack["omega"])
+    for i in range(4):
+        for full, part, name in ((X1, outs[i][0], "x"), (Y, outs[i][1], "y"), (R, outs[i][2], "c")):
+            o, k = lay[name][i]
+            assert np.allclose(full[o:o + k], part, rtol=0, atol=1e-12 * max(1.0, np.abs(part).max() if part.size else 1.0)), (i, name)
+    with pytest.raises(ValueError):
+        compose.fuse(devs, rand_model(1, 0, 0, 0, 0, 2, 1, 1, 0))        # grid with too few disturbance inputs
