@@ -103,6 +103,12 @@ int mld_device_info(char *name, int name_len, int *n_cu, int64_t *hbm_bytes, int
  * n_models x rows x cols row-major, NULL = zeros (the reference pads missing matrices with zeros,
  * mld_model.py:910-928; C must be passed explicitly -- the Python layer applies the C=I default :515-520). */
 int mld_model_create(mld_model_t **out, const mld_dims *dims, int n_models, const double *const *mats);
+/* Time-varying horizon (MldInfo / mld_numeric_tilde, models/mld_model.py:1210-1227; the time-varying branch of
+ * controllers/components/mld_evolution_matrices.py:265-272): every horizon is N_tilde step models, step k acting on
+ * (x(k), v(k)).  `mats` as above with n_horizons x N_tilde stacked models (horizon-major).  The handle then stands
+ * for n_horizons condensed systems: mld_condense* accept only this N_tilde, and problems built on it
+ * (mld_problem_create with the same N_tilde) index horizons through model_idx exactly as they index models. */
+int mld_model_create_tv(mld_model_t **out, const mld_dims *dims, int n_horizons, int N_tilde, const double *const *mats);
 int mld_model_destroy(mld_model_t *);
 
 /* ---- condensing (kernels K1+K2) -----------------------------------------------------------

@@ -134,6 +134,56 @@ def condense(mats, N_tilde):
                 L_x=L_x, L_v=L_v, L_omega=L_w, L_5=L_5, H_x=H_x, H_v=H_v, H_omega=H_w, H_5=H_5, dims=d)
 
 
+def condense_tv(mats_list, N_tilde=None):
+    """Evolution matrices of a time-VARYING horizon: mats_list[k] is the numeric MLD model of horizon step k
+    (`mld_numeric_tilde`, models/mld_model.py:1210-1227; time-varying branch of `_gen_A_pow_tilde`,
+    controllers/components/mld_evolution_matrices.py:265-272).
+
+    The reference's own branch is unreachable (typo at controllers/controller_utils.py:26) and accumulates its
+    products in an order that is only right for a time-invariant model, so there is no reference behaviour to pin;
+    what is restated here is the intent -- the linear time-varying recursion
+        x(k+1) = A_k x(k) + [B1 B2 B3 0]_k v(k) + B4_k w(k) + b5_k ,   y(k) = C_k x(k) + D_k v(k) + ... ,
+        E_k x(k) + F_k v(k) + F4_k w(k) + G_k y(k) <= f5_k
+    written block by block: Phi_x[i] = A_{i-1} ... A_0, Gamma[i][j] = A_{i-1} ... A_{j+1} B_j (j < i), same sign
+    conventions as condense().  With identical step models it reproduces condense() exactly."""
+    N = len(mats_list) if N_tilde is None else N_tilde
+    d = mld_dims(mats_list[0])
+    ms = [pad_mats(m, d) for m in mats_list[:N]]
+    nx, nv, nw, ny, nc = d["nx"], d["nv"], d["nomega"], d["ny"], d["nc"]
+    Bv = [np.hstack([m["B1"], m["B2"], m["B3"], np.zeros((nx, d["nmu"]))]) for m in ms]
+    Dv = [np.hstack([m["D1"], m["D2"], m["D3"], np.zeros((ny, d["nmu"]))]) for m in ms]
+    Fv = [np.hstack([m["F1"], m["F2"], m["F3"], m["Psi"]]) for m in ms]
+    Phi_x = np.zeros((N * nx, nx)); Gv = np.zeros((N * nx, N * nv)); Gw = np.zeros((N * nx, N * nw)); G5 = np.zeros((N * nx, 1))
+    P = np.eye(nx); s5 = np.zeros((nx, 1))
+    for i in range(N):
+        Phi_x[i * nx:(i + 1) * nx] = P
+        G5[i * nx:(i + 1) * nx] = s5
+        s5 = ms[i]["A"] @ s5 + ms[i]["b5"]
+        P = ms[i]["A"] @ P
+    for j in range(N):
+        Pv, Pw = Bv[j], ms[j]["B4"]
+        for i in range(j + 1, N):
+            Gv[i * nx:(i + 1) * nx, j * nv:(j + 1) * nv] = Pv
+            Gw[i * nx:(i + 1) * nx, j * nw:(j + 1) * nw] = Pw
+            Pv, Pw = ms[i]["A"] @ Pv, ms[i]["A"] @ Pw
+    L_x = np.zeros((N * ny, nx)); L_v = np.zeros((N * ny, N * nv)); L_w = np.zeros((N * ny, N * nw)); L_5 = np.zeros((N * ny, 1))
+    H_x = np.zeros((N * nc, nx)); H_v = np.zeros((N * nc, N * nv)); H_w = np.zeros((N * nc, N * nw)); H_5 = np.zeros((N * nc, 1))
+    for i in range(N):
+        m = ms[i]
+        rx, ry, rc = slice(i * nx, (i + 1) * nx), slice(i * ny, (i + 1) * ny), slice(i * nc, (i + 1) * nc)
+        L_x[ry] = m["C"] @ Phi_x[rx]
+        L_v[ry] = m["C"] @ Gv[rx]; L_v[ry, i * nv:(i + 1) * nv] += Dv[i]
+        L_w[ry] = m["C"] @ Gw[rx]; L_w[ry, i * nw:(i + 1) * nw] += m["D4"]
+        L_5[ry] = m["C"] @ G5[rx] + m["d5"]
+        H_x[rc] = -(m["E"] @ Phi_x[rx] + m["G"] @ L_x[ry])
+        H_v[rc] = m["E"] @ Gv[rx] + m["G"] @ L_v[ry]; H_v[rc, i * nv:(i + 1) * nv] += Fv[i]
+        Hw = m["E"] @ Gw[rx] + m["G"] @ L_w[ry]; Hw[:, i * nw:(i + 1) * nw] += m["F4"]
+        H_w[rc] = -Hw
+        H_5[rc] = m["f5"] - (m["E"] @ G5[rx] + m["G"] @ L_5[ry])
+    return dict(Phi_x=Phi_x, Gamma_v=Gv, Gamma_omega=Gw, Gamma_5=G5, L_x=L_x, L_v=L_v, L_omega=L_w, L_5=L_5,
+                H_x=H_x, H_v=H_v, H_omega=H_w, H_5=H_5, dims=d)
+
+
 # ----------------------------------------------------------------------------- objective atoms
 _ATOM_PAT = re.compile(r"(Linear)|(Quadratic)|([L](1|(22)|(inf)))")
 _RATE_PAT = re.compile(r"[dD][^e]")
@@ -324,7 +374,7 @@ def cost_const(const_terms, x0, omega):
 def standard_form(mats, atoms, N_p, N_tilde, nu_l=0, nmu_l=0):
     """Everything the solve needs, for one model:  min 1/2 v'Pv + q(x,w)'v + r  s.t.  G v <= h(x,w),
     mu >= 0, v_i in {0,1} (i in bin).  Constraint form: controllers/controller_base.py:446-452."""
-    evo = condense(mats, N_tilde)
+    evo = condense_tv(mats, N_tilde) if isinstance(mats, (list, tuple)) else condense(mats, N_tilde)   # list = one model per step
     d = evo["dims"]
     weights = build_weights(atoms, d, N_p, N_tilde)
     cost = assemble_cost(weights, evo, d, N_tilde)

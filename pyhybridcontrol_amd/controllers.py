@@ -37,6 +37,19 @@ _EVO = dict(state_input=("Phi_x", "Gamma_v", "Gamma_omega", "Gamma_5"), output=(
 _ROWS = dict(state_input="nx", output="ny", constraint="nc")
 
 
+def check_numeric_tilde(mld_numeric_tilde, N_tilde):
+    """the list of N_tilde numeric step models of a time-varying horizon (mld_numeric_tilde, controller_base.py:311;
+    every step must have the dimensions and variable types of step 0)"""
+    tilde = [m if isinstance(m, MldModel) else MldModel(m) for m in mld_numeric_tilde]
+    if len(tilde) != N_tilde:
+        raise ValueError("mld_numeric_tilde needs one model per horizon step: %d given, N_tilde = %d" % (len(tilde), N_tilde))
+    d0 = tilde[0].mld_info.as_gpu_dims()
+    for k, m in enumerate(tilde):
+        if m.mld_info.as_gpu_dims() != d0:
+            raise ValueError("mld_numeric_tilde[%d] differs from step 0 in its dimensions or variable types" % k)
+    return tilde
+
+
 class MldEvoMatrices(dict):
     """{'state_input'|'output'|'constraint': {name_N_tilde, name_N_p}} computed by kernels K1+K2.
 
@@ -47,12 +60,14 @@ class MldEvoMatrices(dict):
 
     def __init__(self, controller=None, N_p=None, N_tilde=None, mld_numeric_k=None, mld_numeric_tilde=None):
         super(MldEvoMatrices, self).__init__()
-        if mld_numeric_tilde:
-            raise NotImplementedError("time-varying horizons (mld_numeric_tilde) are SURVEY 8f item 3 (next)")
         self._controller = controller
         self.N_p = N_p if N_p is not None else controller.N_p
         self.N_tilde = N_tilde if N_tilde is not None else (controller.N_tilde if controller else self.N_p + 1)
-        self._model = mld_numeric_k if mld_numeric_k is not None else controller.mld_numeric_k
+        if mld_numeric_tilde is None and controller is not None and mld_numeric_k is None:
+            mld_numeric_tilde = controller.mld_numeric_tilde
+        # one model per horizon step (component_base.py:72-81: step 0 then plays the part of mld_numeric_k)
+        self._tilde = check_numeric_tilde(mld_numeric_tilde, self.N_tilde) if mld_numeric_tilde else None
+        self._model = self._tilde[0] if self._tilde else (mld_numeric_k if mld_numeric_k is not None else controller.mld_numeric_k)
         if not isinstance(self._model, MldModel):
             raise ValueError("mld_numeric_k must be an MldModel with mld_type=='numeric'")
         self._gpu_model = None
@@ -76,7 +91,11 @@ class MldEvoMatrices(dict):
 
     def gpu_model(self):
         if self._gpu_model is None:
-            self._gpu_model = gpu.GpuModel([self._model.as_mats()], self._model.mld_info.as_gpu_dims())
+            dims = self._model.mld_info.as_gpu_dims()
+            if self._tilde:
+                self._gpu_model = gpu.GpuModel([[m.as_mats() for m in self._tilde]], dims, time_varying=True)
+            else:
+                self._gpu_model = gpu.GpuModel([self._model.as_mats()], dims)
         return self._gpu_model
 
     def update(self, reset=False, **_):
@@ -172,15 +191,21 @@ class MldSimLog(dict):
 
 class MpcController(object):
     def __init__(self, model=None, x_k=None, omega_tilde_k=None, N_p=None, N_tilde=None, agent=None, mld_numeric=None,
-                 **solver_opts):
+                 mld_numeric_tilde=None, **solver_opts):
         if agent is not None:
             raise NotImplementedError("agent ownership layer (models/agents.py) is out of scope; pass model=")
-        model = model if model is not None else mld_numeric
-        if not isinstance(model, MldModel):
-            model = MldModel(model)
-        self._model = model
         self._N_p = N_p if N_p is not None else 0
         self._N_tilde = N_tilde if N_tilde is not None else self._N_p + 1
+        # time-varying horizon: one numeric model per step; the reference keeps the attribute (controller_base.py:175,
+        # 306-312) but never sets it -- here it is a constructor argument and a settable property
+        self._tilde = check_numeric_tilde(mld_numeric_tilde, self._N_tilde) if mld_numeric_tilde else None
+        model = model if model is not None else mld_numeric
+        if model is None and self._tilde:
+            model = self._tilde[0]
+        if not isinstance(model, MldModel):
+            model = MldModel(model)
+        self._sim_model = model                    # the plant sim_step_k evolves (controller_base.py:235)
+        self._model = self._tilde[0] if self._tilde else model
         self._solver_opts = dict(solver_opts)
         self._sim_log = MldSimLog()
         self._solve_time_overall = 0
@@ -216,6 +241,30 @@ class MpcController(object):
     @property
     def mld_numeric_k(self):
         return self._model
+
+    @property
+    def mld_numeric_tilde(self):
+        return self._tilde
+
+    @mld_numeric_tilde.setter
+    def mld_numeric_tilde(self, value):
+        """a new horizon of step models (e.g. shifted by one step between MPC iterations): same shapes, so the cost atoms,
+        the logs and the state are kept; the condensed maps and the GPU problem are rebuilt at the next build()"""
+        tilde = check_numeric_tilde(value, self._N_tilde) if value else None
+        new0 = tilde[0] if tilde else self._sim_model
+        if new0.mld_info.as_gpu_dims() != self._model.mld_info.as_gpu_dims():
+            raise ValueError("mld_numeric_tilde must keep the controller's dimensions and variable types")
+        self._tilde, self._model = tilde, new0
+        self._mld_evo_matrices = None
+        if self._problem is not None:
+            self._problem.close(); self._problem = None
+        if getattr(self, "_epi_model", None) is not None:
+            self._epi_model.close(); self._epi_model = None
+        self._build_required = True
+
+    def _step_mats(self):
+        """per-step matrices of a time-varying horizon, or None"""
+        return [m.as_mats() for m in self._tilde] if self._tilde else None
 
     @property
     def mld_info_k(self):
@@ -337,7 +386,12 @@ class MpcController(object):
         W = self._std_obj_atoms.weights
         dims0, N = self._model.mld_info.as_gpu_dims(), self._N_tilde
         rv = epigraph.rate_vars(W)
-        mats1, dims1, info = epigraph.augment_rates(self._model.as_mats(), dims0, rv) if rv else (self._model.as_mats(), dims0, {})
+        steps = self._step_mats()
+        if steps:                              # time-varying horizon: the same augmentation of every step model
+            aug = [epigraph.augment_rates(m, dims0, rv) if rv else (m, dims0, {}) for m in steps]
+            mats1, dims1, info = [a[0] for a in aug], aug[0][1], aug[0][2]
+        else:
+            mats1, dims1, info = epigraph.augment_rates(self._model.as_mats(), dims0, rv) if rv else (self._model.as_mats(), dims0, {})
         blocks = epigraph.plan(W, dims0, N)
         for b in blocks:                      # atoms on x / y act on the original entries, not on lag states / rate outputs
             if b["var"] in ("x", "y"):
@@ -382,8 +436,13 @@ class MpcController(object):
             self._epi_blocks, self._epi_sig, self._vmap = blocks, sig, None
             self._rate_vars, self._rate_info, self._rate_dims = rv, info, dims1
             if blocks or rv:
-                mats2, self._epi_dims, _ = epigraph.augment(mats1, dims1, blocks)
-                self._epi_model = gpu.GpuModel([mats2], self._epi_dims)
+                if isinstance(mats1, list):
+                    aug = [epigraph.augment(m, dims1, blocks) for m in mats1]
+                    self._epi_dims = aug[0][1]
+                    self._epi_model = gpu.GpuModel([[a[0] for a in aug]], self._epi_dims, time_varying=True)
+                else:
+                    mats2, self._epi_dims, _ = epigraph.augment(mats1, dims1, blocks)
+                    self._epi_model = gpu.GpuModel([mats2], self._epi_dims)
                 self._problem = gpu.GpuProblem(self._epi_model, self._N_p, self._N_tilde, self._signed(self._problem_cost(cost)), **self._solver_opts)
             else:
                 self._epi_dims = dims1

@@ -38,7 +38,8 @@ struct CondLayout {
 
 struct mld_model {
     mld_dims dims;
-    int n_models;
+    int n_models;         // horizons: with tv_N > 0 every horizon is tv_N consecutive step models in d_mats / h_mats / d_pack
+    int tv_N;             // 0 = time-invariant (one model per horizon)
     int nv;
     // device copies of the 20 system matrices, each n_models x rows x cols (NULL if zero-sized)
     double *d_mats[20];

@@ -64,9 +64,23 @@ static void mat_shape(const mld_dims &d, int id, int *r, int *c)
     *r = rows[id]; *c = cols[id];
 }
 
+static int model_create_impl(mld_model_t **out, const mld_dims *dims, int n_sets, int tv_N, const double *const *mats);
+
 int mld_model_create(mld_model_t **out, const mld_dims *dims, int n_models, const double *const *mats)
 {
-    if (!out || !dims || n_models < 1 || !mats) { mld_set_error("mld_model_create: bad arguments"); return MLD_ERR_INVALID; }
+    return model_create_impl(out, dims, n_models, 0, mats);
+}
+
+int mld_model_create_tv(mld_model_t **out, const mld_dims *dims, int n_horizons, int N_tilde, const double *const *mats)
+{
+    if (N_tilde < 1) { mld_set_error("mld_model_create_tv: N_tilde must be >= 1"); return MLD_ERR_INVALID; }
+    return model_create_impl(out, dims, n_horizons, N_tilde, mats);
+}
+
+static int model_create_impl(mld_model_t **out, const mld_dims *dims, int n_sets, int tv_N, const double *const *mats)
+{
+    const int n_models = n_sets * (tv_N > 0 ? tv_N : 1);      // step models uploaded
+    if (!out || !dims || n_sets < 1 || !mats) { mld_set_error("mld_model_create: bad arguments"); return MLD_ERR_INVALID; }
     const mld_dims &d = *dims;
     if (d.nx < 0 || d.nu < 0 || d.ndelta < 0 || d.nz < 0 || d.nmu < 0 || d.nomega < 0 || d.ny < 0 || d.nc < 0 ||
         d.nu_l < 0 || d.nu_l > d.nu || d.nmu_l < 0 || d.nmu_l > d.nmu) {
@@ -74,7 +88,7 @@ int mld_model_create(mld_model_t **out, const mld_dims *dims, int n_models, cons
     }
     if (mld_device_count() <= 0) { mld_set_error("no HIP device (libmldgpu has no CPU fallback)"); return MLD_ERR_NO_DEVICE; }
     mld_model *m = new mld_model();
-    m->dims = d; m->n_models = n_models; m->nv = d.nu + d.ndelta + d.nz + d.nmu;
+    m->dims = d; m->n_models = n_sets; m->tv_N = tv_N; m->nv = d.nu + d.ndelta + d.nz + d.nmu;
     m->cond_N = -1; m->d_blocks = nullptr; m->d_pack = nullptr; m->pack_len = 0;
     for (int k = 0; k < 12; ++k) m->d_out[k] = nullptr;
     m->h_mats.resize(20);

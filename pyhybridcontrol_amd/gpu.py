@@ -28,12 +28,20 @@ def evo_shapes(dims, N):
 class GpuModel(object):
     """n_models same-shaped numeric MLD systems resident in HBM (mld_model_create)."""
 
-    def __init__(self, mats_list, dims):
+    def __init__(self, mats_list, dims, time_varying=False):
         """mats_list: list of dicts name -> 2-D array (missing / empty = zeros); dims: dict with
-        nx,nu,ndelta,nz,nmu,nomega,ny,nc,nu_l,nmu_l"""
+        nx,nu,ndelta,nz,nmu,nomega,ny,nc,nu_l,nmu_l.
+        time_varying: mats_list is a list of horizons, each a list of N_tilde step models (mld_model_create_tv)."""
         if isinstance(mats_list, dict):
             mats_list = [mats_list]
         self.dims = {k: int(dims.get(k, 0)) for k in ("nx", "nu", "ndelta", "nz", "nmu", "nomega", "ny", "nc", "nu_l", "nmu_l")}
+        self.tv_N = 0
+        n_sets = len(mats_list)
+        if time_varying:
+            self.tv_N = len(mats_list[0])
+            if self.tv_N < 1 or any(len(h) != self.tv_N for h in mats_list):
+                raise ValueError("every horizon needs the same number (>= 1) of step models")
+            mats_list = [m for h in mats_list for m in h]
         self.n_models = len(mats_list)
         self.nv = self.dims["nu"] + self.dims["ndelta"] + self.dims["nz"] + self.dims["nmu"]
         self._keep = []
@@ -61,7 +69,11 @@ class GpuModel(object):
                 ptrs[k] = None
         d = _lib.Dims(**self.dims)
         self._h = C.c_void_p()
-        check(_lib.load().mld_model_create(C.byref(self._h), C.byref(d), self.n_models, ptrs))
+        if self.tv_N:
+            check(_lib.load().mld_model_create_tv(C.byref(self._h), C.byref(d), n_sets, self.tv_N, ptrs))
+        else:
+            check(_lib.load().mld_model_create(C.byref(self._h), C.byref(d), self.n_models, ptrs))
+        self.n_models = n_sets
         self._keep = []
 
     def close(self):

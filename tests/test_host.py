@@ -353,3 +353,20 @@ def test_fused_grid_model_equals_sequential_evaluation():
             assert np.allclose(full[o:o + k], part, rtol=0, atol=1e-12 * max(1.0, np.abs(part).max() if part.size else 1.0)), (i, name)
     with pytest.raises(ValueError):
         compose.fuse(devs, rand_model(1, 0, 0, 0, 0, 2, 1, 1, 0))        # grid with too few disturbance inputs
+
+
+def test_check_numeric_tilde_validates_the_step_models():
+    """time-varying horizon (mld_numeric_tilde): one numeric model per step, all with step 0's shapes and types"""
+    import pyhybridcontrol_amd as phc
+    from pyhybridcontrol_amd.controllers import check_numeric_tilde
+    mk = lambda a, **kw: phc.MldModel(A=[[a]], B1=[[1.0]], E=[[1.0]], F1=[[0.0]], f5=[[2.0]], **kw)
+    steps = [mk(0.9), mk(0.8), mk(0.7)]
+    out = check_numeric_tilde(steps, 3)
+    assert [m["A"][0, 0] for m in out] == [0.9, 0.8, 0.7]
+    with pytest.raises(ValueError, match="one model per horizon step"):
+        check_numeric_tilde(steps, 4)
+    with pytest.raises(ValueError, match="differs from step 0"):
+        check_numeric_tilde([mk(0.9), mk(0.8, nu_l=1), mk(0.7)], 3)
+    two_rows = phc.MldModel(A=[[0.9]], B1=[[1.0]], E=[[1.0], [-1.0]], F1=[[0.0], [0.0]], f5=[[2.0], [2.0]])
+    with pytest.raises(ValueError, match="differs from step 0"):
+        check_numeric_tilde([mk(0.9), two_rows, mk(0.7)], 3)

@@ -60,3 +60,35 @@ def test_objective_weights_match_reference():
             assert np.allclose(val, z[key], rtol=0, atol=1e-14), key
             seen += 1
     assert seen >= 10
+
+
+# ---- time-varying horizons: condense_tv ---------------------------------------------------------------
+@pytest.mark.parametrize("path", g.case_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_condense_tv_with_identical_steps_reproduces_reference_golden(path):
+    z, mats, dims, N_p, N_t = g.load_case(path)
+    evo = cn.condense_tv([mats] * N_t)
+    for name in g.EVO_NAMES:
+        g.check_evo(z, name, evo[name], dims)
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3"])
+def test_condense_tv_is_the_step_by_step_evolution(name):
+    """the condensed maps of a time-varying horizon against the recursion they summarise, simulated step by step"""
+    import _tv
+    from pyhybridcontrol_amd import synthetic as syn
+    wl = syn.make_workload(name, batch=1)
+    ag = wl["agents"][0]
+    N = wl["N_tilde"]
+    ms = _tv.step_models(ag["mats"], N, seed=3, strength=0.2)
+    evo = cn.condense_tv(ms)
+    d = evo["dims"]
+    rng = np.random.default_rng(5)
+    x0 = rng.normal(size=d["nx"]); V = rng.normal(size=(N, d["nv"])); W = rng.normal(size=(N, d["nomega"]))
+    xs, ys, res = _tv.simulate(ms, d, x0, V, W)
+    v, w, x = V.reshape(-1, 1), W.reshape(-1, 1), x0.reshape(-1, 1)
+    sx = evo["Phi_x"] @ x + evo["Gamma_v"] @ v + evo["Gamma_omega"] @ w + evo["Gamma_5"]
+    sy = evo["L_x"] @ x + evo["L_v"] @ v + evo["L_omega"] @ w + evo["L_5"]
+    sr = evo["H_v"] @ v - (evo["H_x"] @ x + evo["H_omega"] @ w + evo["H_5"])
+    for a, b in ((sx, xs), (sy, ys), (sr, res)):
+        assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+    assert np.abs(evo["Gamma_v"] - cn.condense(ag["mats"], N)["Gamma_v"]).max() > 1e-3      # the horizon really varies
