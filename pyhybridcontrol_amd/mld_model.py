@@ -305,3 +305,42 @@ class MldModel(object):
                           np.zeros((1, info.nomega)) if row(omega_k, info.nomega) is None else row(omega_k, info.nomega),
                           delta=row(delta_k, info.ndelta), z=row(z_k, info.nz), mu=row(mu_k, info.nmu))
         return tuple(out[n].reshape(-1, 1) for n in ("delta", "z", "mu"))
+
+
+def gen_schedule_params_tilde(N_tilde, param_struct, schedule_params_evo=None, **kwargs):
+    """{name: [value_0 .. value_{N_tilde-1}]} -> one parameter subset per horizon step
+    (PvMldSystemModel._gen_schedule_params_tilde, models/mld_model.py:1181-1208; same errors)."""
+    evo = dict(schedule_params_evo) if schedule_params_evo is not None else {}
+    evo.update({k: v for k, v in kwargs.items() if k in param_struct})
+    if not evo:
+        return None
+    tilde = [dict.fromkeys(evo.keys()) for _ in range(N_tilde)]
+    for name, values in evo.items():
+        if name not in param_struct:
+            raise ValueError("Invalid schedule_param_name:'%s' in schedule_params_evo, name needs to be present in "
+                             "param_struct." % name)
+        if len(values) != N_tilde:
+            raise ValueError("Invalid length:'%d' for schedule_param_tilde:'%s', length of schedule_param_tilde must be "
+                             "equal to N_tilde:'%d'" % (len(values), name, N_tilde))
+        for k, v in enumerate(values):
+            tilde[k][name] = v
+    return tilde
+
+
+def get_mld_numeric_tilde(get_mld_numeric, N_tilde, param_struct=None, schedule_params_tilde=None):
+    """The step models of a time-varying horizon (PvMldSystemModel.get_mld_numeric_tilde, models/mld_model.py:1210-1227).
+    ``get_mld_numeric(param_struct)`` is the numeric model factory -- the reference's is the lambdified symbolic model,
+    which is outside this package; any callable returning an MldModel (or its matrices) does.  Without a schedule the
+    one model is repeated, as in the reference."""
+    base = dict(param_struct or {})
+
+    def make(ps):
+        m = get_mld_numeric(ps)
+        return m if isinstance(m, MldModel) else MldModel(m)
+
+    if schedule_params_tilde is None:
+        return [make(base)] * N_tilde
+    if len(schedule_params_tilde) != N_tilde:
+        raise ValueError("Invalid length:'%d' for param_struct_tilde.schedule_param_tilde, length of schedule_param_tilde "
+                         "must be equal to N_tilde:'%d'" % (len(schedule_params_tilde), N_tilde))
+    return [make(dict(base, **schedule_params_tilde[k])) for k in range(N_tilde)]

@@ -370,3 +370,23 @@ def test_check_numeric_tilde_validates_the_step_models():
     two_rows = phc.MldModel(A=[[0.9]], B1=[[1.0]], E=[[1.0], [-1.0]], F1=[[0.0], [0.0]], f5=[[2.0], [2.0]])
     with pytest.raises(ValueError, match="differs from step 0"):
         check_numeric_tilde([mk(0.9), two_rows, mk(0.7)], 3)
+
+
+def test_schedule_params_make_the_step_models_of_a_horizon():
+    """gen_schedule_params_tilde / get_mld_numeric_tilde (models/mld_model.py:1181-1227) over a numeric model factory"""
+    import pyhybridcontrol_amd as phc
+    ps = dict(a=0.9, b=1.0)
+    make = lambda p: phc.MldModel(A=[[p["a"]]], B1=[[p["b"]]], E=[[1.0]], F1=[[0.0]], f5=[[2.0]])
+    assert phc.gen_schedule_params_tilde(3, ps) is None
+    sched = phc.gen_schedule_params_tilde(3, ps, dict(a=[0.9, 0.8, 0.7]), b=[1.0, 2.0, 3.0], ignored=[1, 2, 3])
+    assert sched == [dict(a=0.9, b=1.0), dict(a=0.8, b=2.0), dict(a=0.7, b=3.0)]
+    with pytest.raises(ValueError, match="needs to be present in param_struct"):
+        phc.gen_schedule_params_tilde(3, ps, dict(c=[1, 2, 3]))
+    with pytest.raises(ValueError, match="must be equal to N_tilde"):
+        phc.gen_schedule_params_tilde(3, ps, dict(a=[1, 2]))
+    tilde = phc.get_mld_numeric_tilde(make, 3, ps, sched)
+    assert [(m["A"][0, 0], m["B1"][0, 0]) for m in tilde] == [(0.9, 1.0), (0.8, 2.0), (0.7, 3.0)]
+    same = phc.get_mld_numeric_tilde(make, 3, ps)
+    assert same[0] is same[1] is same[2] and same[0]["A"][0, 0] == 0.9
+    with pytest.raises(ValueError, match="must be equal to N_tilde"):
+        phc.get_mld_numeric_tilde(make, 4, ps, sched)
