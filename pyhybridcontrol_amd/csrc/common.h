@@ -54,6 +54,7 @@ struct mld_model {
     CondLayout lay;
     double *d_blocks;     // n_models x blk_stride
     double *d_out[12];    // materialised matrices, each n_models x out_size[k]
+    double *d_tvQ, *d_tvS; // time-varying horizons: products Q(i,j) (triangular) and the affine chain, written by k_tv_chain
 };
 
 // matrix order in d_mats

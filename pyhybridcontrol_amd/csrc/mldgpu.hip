@@ -89,7 +89,7 @@ static int model_create_impl(mld_model_t **out, const mld_dims *dims, int n_sets
     if (mld_device_count() <= 0) { mld_set_error("no HIP device (libmldgpu has no CPU fallback)"); return MLD_ERR_NO_DEVICE; }
     mld_model *m = new mld_model();
     m->dims = d; m->n_models = n_sets; m->tv_N = tv_N; m->nv = d.nu + d.ndelta + d.nz + d.nmu;
-    m->cond_N = -1; m->d_blocks = nullptr; m->d_pack = nullptr; m->pack_len = 0;
+    m->cond_N = -1; m->d_blocks = nullptr; m->d_pack = nullptr; m->pack_len = 0; m->d_tvQ = m->d_tvS = nullptr;
     for (int k = 0; k < 12; ++k) m->d_out[k] = nullptr;
     m->h_mats.resize(20);
     for (int k = 0; k < 20; ++k) {
@@ -153,6 +153,8 @@ int mld_model_destroy(mld_model_t *m)
     for (int k = 0; k < 20; ++k) if (m->d_mats[k]) (void)hipFree(m->d_mats[k]);
     if (m->d_blocks) (void)hipFree(m->d_blocks);
     if (m->d_pack) (void)hipFree(m->d_pack);
+    if (m->d_tvQ) (void)hipFree(m->d_tvQ);
+    if (m->d_tvS) (void)hipFree(m->d_tvS);
     for (int k = 0; k < 12; ++k) if (m->d_out[k]) (void)hipFree(m->d_out[k]);
     delete m;
     return MLD_OK;

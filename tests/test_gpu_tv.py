@@ -25,8 +25,12 @@ def test_identical_steps_reproduce_reference_golden(path):
     m.close()
 
 
+@pytest.mark.parametrize("chain_only", [False, True], ids=["wide", "chain"])
 @pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4"])
-def test_condense_tv_matches_oracle(name):
+def test_condense_tv_matches_oracle(name, chain_only, monkeypatch):
+    """both device paths: k_tv_chain + k_tv_rows (shapes that fit LDS) and the single-kernel k_condense_tv kept for the rest"""
+    if chain_only:
+        monkeypatch.setenv("MLD_TV_CHAIN_ONLY", "1")
     wl = syn.make_workload(name, batch=1, n_agents=3)
     N, dims = wl["N_tilde"], wl["agents"][0]["dims"]
     horizons = [_tv.step_models(a["mats"], N, seed=11 + i, strength=0.2) for i, a in enumerate(wl["agents"])]
