@@ -235,7 +235,7 @@ def main():
         cols = N_t * nv + nx + N_t * nw + 1
         bytes_cond = 8.0 * (N_t * (nc + nx + ny) * cols + (nx + ny + nc) * (nx + nv + nw + 1) + nc * ny)
         ach = args.agents * bytes_cond / (ms * 1e-3) / 1e9
-        result["roofline_condense"] = {"kernel": "k_condense_blocks+k_condense_flat", "bound": "hbm", "achieved": round(ach, 1),
+        result["roofline_condense"] = {"kernel": "k_condense_model+k_condense_flat", "bound": "hbm", "achieved": round(ach, 1),
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                        "bytes_per_model": int(bytes_cond), "models": args.agents, "kernel_ms": round(ms, 4)}
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:    # CPU leg: rank 0 at N=1 only

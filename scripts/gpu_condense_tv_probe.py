@@ -1,4 +1,4 @@
-"""k_condense_tv (one model per horizon step) beside k_condense_blocks+k_condense_flat on the bench shard's models:
+"""k_condense_tv (one model per horizon step) beside K1+K2 (k_condense_model + k_condense_flat) on the bench shard's models:
 kernel milliseconds (HIP events inside the library) and algorithmic GB/s (outputs written + step models read)."""
 import os, sys
 import numpy as np

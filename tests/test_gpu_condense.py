@@ -12,8 +12,13 @@ from pyhybridcontrol_amd import gpu, synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("per_block", [False, True], ids=["k1-model", "k1-block"])
 @pytest.mark.parametrize("path", g.case_files(), ids=lambda p: os.path.basename(p)[:-4])
-def test_condense_gpu_matches_reference_golden(path):
+def test_condense_gpu_matches_reference_golden(path, per_block, monkeypatch):
+    """both K1 variants: k_condense_model (all blocks of a model in one workgroup) and k_condense_blocks (kept for shapes
+    that do not fit LDS)"""
+    if per_block:
+        monkeypatch.setenv("MLD_K1_PER_BLOCK", "1")
     z, mats, dims, N_p, N_t = g.load_case(path)
     m = gpu.GpuModel([mats], dims)
     evo = m.condense(N_t)
