@@ -333,3 +333,44 @@ def test_maximum_size_cfg5_condense_and_solve_certificates():
         check_solution(ag, wl, s, out["v"][s], out["obj"][s])
         assert out["lower_bound"][s] <= out["obj"][s] + 1e-6
     p.close(); m.close()
+
+
+def test_closed_loop_receding_horizon_matches_highs_every_step():
+    """twelve MPC iterations in closed loop (solve -> feedback -> sim_step_k -> shifted disturbance forecast): at every step the
+    GPU objective equals HiGHS on the same condensed problem, the applied input is the first step of the plan and the state the
+    controller carries forward is the model's own evolution"""
+    import pyhybridcontrol_amd as phc
+    from scipy.optimize import milp, LinearConstraint, Bounds
+    model = phc.MldModel(A=[[0.9970371127900564]], B1=[[4.298192277481107]], B4=[[-179.73320827515]],
+                         b5=[[0.07407218024859108]], E=[[1], [-1]], F1=[[0], [0]], Psi=[[-1, 0], [0, -1]],
+                         f5=[[65.0], [-50.0]], nu_l=1, ts=900)
+    N_p, steps = 8, 12
+    N = N_p + 1
+    rng = np.random.default_rng(17)
+    draw = rng.uniform(0.0, 0.02, steps + N)            # hot-water draw forecast
+    price = 1.0 + 2.0 * (np.arange(steps + N) % 6 < 2)
+    ctrl = phc.MpcController(model, N_p=N_p)
+    sf0 = None
+    x = np.array([51.0])
+    for k in range(steps):
+        q_u = (0.75 * price[k:k + N]).reshape(-1, 1)
+        ctrl.set_std_obj_atoms(q_u=q_u, q_mu=[90.0, 90.0])
+        ctrl.build()
+        om = draw[k:k + N]
+        obj = ctrl.solve(k, x_k=x, omega_tilde_k=om)
+        sf = cn.standard_form(model.as_mats(), {"q_u": q_u, "q_mu": np.array([[90.0], [90.0]])}, N_p, N, nu_l=1)
+        h, q = cn.rhs(sf["evo"], x, om), cn.lin_cost(sf["cost"], x, om)
+        r = cn.cost_const(sf["cost"]["const_terms"], x, om)
+        ref = milp(q, constraints=LinearConstraint(sf["G"], -np.inf, h), integrality=sf["is_bin"].astype(int),
+                   bounds=Bounds(sf["lb"], sf["ub"]))
+        assert ref.status == 0 and abs(obj - (ref.fun + r)) <= 1e-6 * max(1.0, abs(obj)), (k, obj, ref.fun + r)
+        v = ctrl.v_N_tilde.ravel()
+        assert np.all(sf["G"] @ v <= h + 1e-7)
+        fb = ctrl.feedback(k)
+        assert fb["u"][0, 0] == v[0] and fb["u"][0, 0] in (0.0, 1.0)
+        sim = ctrl.sim_step_k(k)
+        x_next = model["A"] @ x.reshape(1, 1) + model["B1"] * v[0] + model["B4"] * om[0] + model["b5"]
+        assert abs(sim["x_k1"][0, 0] - x_next[0, 0]) <= 1e-9 and abs(ctrl.x_k[0, 0] - x_next[0, 0]) <= 1e-9
+        x = np.array([x_next[0, 0]])
+    assert sorted(ctrl.sim_log.keys()) == list(range(steps))
+    assert 49.0 <= x[0] <= 66.0                                           # the thermostat band held (softly) over the run
