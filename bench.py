@@ -154,7 +154,15 @@ def main():
         else:
             ids = [RcclGather.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            gatherer = RcclGather(world, rank, ids[0])
+            try:
+                gatherer = RcclGather(world, rank, ids[0])
+            except Exception as e:      # noqa: BLE001 -- every rank must take the same path: agreed below
+                print("rank %d: libmldgpu communicator failed (%s)" % (rank, e), file=sys.stderr)
+            import torch
+            ok = torch.tensor([1 if gatherer is not None else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:     # the same RCCL all-gather through torch.distributed's communicator
+                gatherer = TorchGather(dist)
 
     def sync():
         if world > 1:
@@ -222,7 +230,8 @@ def main():
                               "node_limit": int((status == 2).sum()), "numerical": int((status == 3).sum())},
                    "no_incumbent": int((~fin).sum()), "median_gap_of_limited": (round(float(np.nanmedian(gap[status == 2])), 5) if (status == 2).any() else 0.0),
                    "nodes_per_instance": round(float(out["nodes"].mean()), 1), "pivots_per_instance": round(pivots / n_local, 1),
-                   "pivots_per_s": round(pivots / (kernel_ms * 1e-3)), "rhs_ms": round(float(np.mean([s["rhs_ms"] for s in stats])), 3)},
+                   "pivots_per_s": round(pivots / (kernel_ms * 1e-3)), "rhs_ms": round(float(np.mean([s["rhs_ms"] for s in stats])), 3),
+                   "result_gather": (None if gatherer is None else type(gatherer).__name__)},
         "roofline": {"kernel": "k_solve", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(upd_bytes), "io_minimum_bytes_per_launch": int(io_bytes),

@@ -56,9 +56,11 @@ class TorchGather(object):
     def all_gather(self, arr):
         import torch
         t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
+        if self.dist.get_backend() == "nccl":            # RCCL moves device buffers only
+            t = t.cuda()
         outs = [torch.zeros_like(t) for _ in range(self.world)]
         self.dist.all_gather(outs, t)
-        return [o.numpy() for o in outs]
+        return [o.cpu().numpy() for o in outs]
 
 
 def gather_sharded(local, total, rank, world, gatherer):
