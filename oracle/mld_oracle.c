@@ -239,6 +239,7 @@ typedef struct {
     long pivots, max_pivots;
     int refactors;
     double *tmp_col, *tmp_row;
+    double *dw;           /* dual devex reference weights of the rows (Forrest & Goldfarb 1992), reset at every dual simplex entry */
     /* convex-QP relaxations by simplicial decomposition (P != NULL) */
     const double *P;      /* scaled Hessian n x n (NULL = linear cost) */
     double *Y, *PY, *Hm, *cm, *wm, *gcost, *vcur, *Pv;
@@ -339,6 +340,11 @@ static void pivot(dict_t *t, int r, int c, double leave_value)
     for (int i = 0; i < m; ++i) t->xB[i] -= colc[i] * theta;
     const double enter_val = t->xN[c] + theta;
     const double inv = 1.0 / p;
+    {   /* devex: w_i = max(w_i, (alpha_iq / alpha_rq)^2 w_r) on the rows the pivot touches, w_r = max(w_r / alpha_rq^2, 1) */
+        const double wr = t->dw[r];
+        for (int i = 0; i < m; ++i) { if (i == r || colc[i] == 0.0) continue; const double f = colc[i] * inv, c2 = f * f * wr; if (c2 > t->dw[i]) t->dw[i] = c2; }
+        t->dw[r] = fmax(wr * inv * inv, 1.0);
+    }
     for (int k = 0; k <= n; ++k) rowr[k] *= inv;
     rowr[c] = inv;
     colc[r] = 0.0;
@@ -389,6 +395,7 @@ static double check_residual(const dict_t *t)
 
 static void refactor(dict_t *t)
 {
+    for (int i = 0; i < t->mcap; ++i) t->dw[i] = 1.0;
     const int n = t->n, m = t->m, ld = t->ld;
     t->refactors++;
     unsigned char *want = (unsigned char *)calloc(n + 1, 1);       /* structurals that must be basic */
@@ -451,6 +458,7 @@ static int dual_simplex(dict_t *t, double cutoff)
     const int n = t->n, ld = t->ld;
     const int m = t->m;
     memset(t->skip, 0, (size_t)t->mcap);
+    for (int i = 0; i < t->mcap; ++i) t->dw[i] = 1.0;     /* new reference framework: the current basis */
     int stall = 0;
     double last_obj = -INFINITY;
     const double *d = t->D + (size_t)t->mcap * ld;
@@ -464,13 +472,17 @@ static int dual_simplex(dict_t *t, double cutoff)
         const double cur = objective(t);
         if (cur > last_obj + 1e-12 * fmax(1.0, fabs(cur))) { stall = 0; last_obj = cur; } else stall++;
         const int bland = stall > 30;
-        int r = -1; double worst = ORC_PTOL; int rb = -1; int rb_id = 0x7fffffff;
+        /* leaving row: dual devex pricing, largest violation^2 / weight (smallest variable id while stalling) */
+        int r = -1; double best_sc = 0.0; int rb = -1; int rb_id = 0x7fffffff;
         for (int i = 0; i < m; ++i) {
             if (t->skip[i]) continue;
             const int j = t->basic[i];
             const double v = fmax(t->lo[j] - t->xB[i], t->xB[i] - t->hi[j]);
-            if (v > worst) { worst = v; r = i; }
-            if (v > ORC_PTOL && j < rb_id) { rb_id = j; rb = i; }
+            if (v > ORC_PTOL) {
+                const double sc = v * v / t->dw[i];
+                if (sc > best_sc) { best_sc = sc; r = i; }
+                if (j < rb_id) { rb_id = j; rb = i; }
+            }
         }
         if (r < 0) {
             checked_at = t->pivots;
@@ -1044,7 +1056,7 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
     t->where = (int *)calloc(t->ntot + 1, sizeof(int));
     t->at_upper = (unsigned char *)calloc(n + 1, 1); t->is_int = (unsigned char *)calloc(n + 1, 1);
     t->skip = (unsigned char *)calloc(t->mcap + 1, 1);
-    t->tmp_col = dalloc(t->mcap + 1); t->tmp_row = dalloc(n + 1);
+    t->tmp_col = dalloc(t->mcap + 1); t->tmp_row = dalloc(n + 1); t->dw = dalloc(t->mcap + 1);
     memcpy(t->is_int, is_bin, n);
     equilibrate(G, m, n, t->is_int, t->rs, t->cs);
     for (int i = 0; i < m; ++i) {
@@ -1345,7 +1357,7 @@ done:
     *obj_out = have ? best : INFINITY;
     free(lb); free(ub); free(t->D); free(t->Gx); free(t->hx); free(t->q); free(t->rs); free(t->cs); free(t->lo);
     free(t->hi); free(t->xB); free(t->xN); free(t->basic); free(t->nonbasic); free(t->where); free(t->at_upper);
-    free(t->is_int); free(t->skip); free(t->tmp_col); free(t->tmp_row); free(bins); free(root_lo); free(root_hi);
+    free(t->is_int); free(t->skip); free(t->tmp_col); free(t->tmp_row); free(t->dw); free(bins); free(root_lo); free(root_hi);
     free(xs); free(xo); free(stk_j); free(stk_first); free(stk_second); free(sv_j); free(sv_lo); free(sv_hi);
     return status;
 }
