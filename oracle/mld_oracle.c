@@ -13,7 +13,8 @@
  *         controllers/controller_base.py:509 ; variable layout controllers/components/variables.py:189-243
  *       Gurobi is third-party, proprietary, un-pinned and absent from /root/reference; what is
  *       restated here is the published textbook algorithm: bounded dual simplex on a dense
- *       dictionary with a Harris ratio test (Chvatal 1983; Harris 1973), Gomory mixed-integer cut
+ *       dictionary with dual devex pricing (Forrest/Goldfarb 1992) and a Harris ratio test (Chvatal 1983;
+ *       Harris 1973), Gomory mixed-integer cut
  *       rounds at the root (Gomory 1960; Balas/Ceria/Cornuejols/Natraj 1996) together with complemented
  *       mixed-integer rounding cuts on the original rows (Marchand/Wolsey 2001), row-activity bound
  *       propagation (Savelsbergh 1994), depth-first LP-based branch-and-bound (Land/Doig 1960) with
