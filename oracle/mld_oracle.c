@@ -270,6 +270,27 @@ static void equilibrate(const double *G, int m, int n, const unsigned char *is_i
     free(cmax);
 }
 
+/* Rows that cannot bind under the ROOT bounds (largest activity <= right-hand side): their slack is basic in the slack basis,
+ * never violates its bound and so never leaves; nothing reads such a row again (cuts substitute rows of basic STRUCTURALS,
+ * verification goes to the original rows), so the pivots need not maintain it: bit 1 of skip[].  Bounds only tighten below
+ * the root.  Not with a quadratic cost: the primal simplex of the QP relaxations ratio-tests every row. */
+static void mark_dead(dict_t *t, int m0, int enable)
+{
+    const int n = t->n;
+    memset(t->skip, 0, (size_t)t->mcap);
+    if (!enable) return;
+    for (int i = 0; i < m0; ++i) {
+        const double *g = t->Gx + (size_t)i * n;
+        double act = 0.0; int inf = 0;
+        for (int j = 0; j < n; ++j) {
+            const double gj = g[j];
+            if (gj > 0.0) { if (t->hi[j] < 0.5 * ORC_BIG) act += gj * t->hi[j]; else inf = 1; }
+            else if (gj < 0.0) { if (t->lo[j] > -0.5 * ORC_BIG) act += gj * t->lo[j]; else inf = 1; }
+        }
+        if (!inf && act <= t->hx[i] - 1e-7) t->skip[i] = 2;
+    }
+}
+
 static void reset_dictionary(dict_t *t)
 {
     const int n = t->n, ld = t->ld;
@@ -337,7 +358,7 @@ static void pivot(dict_t *t, int r, int c, double leave_value)
     const double p = rowr[c];
     const double theta = (t->xB[r] - leave_value) / p;
     double *colc = t->tmp_col;
-    for (int i = 0; i < m; ++i) colc[i] = D[(size_t)i * ld + c];
+    for (int i = 0; i < m; ++i) colc[i] = (t->skip[i] & 2) ? 0.0 : D[(size_t)i * ld + c];   /* rows that can never bind are not maintained */
     for (int i = 0; i < m; ++i) t->xB[i] -= colc[i] * theta;
     const double enter_val = t->xN[c] + theta;
     const double inv = 1.0 / p;
@@ -383,6 +404,7 @@ static double check_residual(const dict_t *t)
     for (int r = 0; r < t->m; ++r) if (t->basic[r] < n) x[t->basic[r]] = t->xB[r];
     double worst = 0;
     for (int i = 0; i < t->m; ++i) {
+        if (t->skip[i] & 2) continue;
         const double *g = t->Gx + (size_t)i * n;
         double s = t->hx[i];
         for (int j = 0; j < n; ++j) s -= g[j] * x[j];
@@ -458,8 +480,7 @@ static int dual_simplex(dict_t *t, double cutoff)
 {
     const int n = t->n, ld = t->ld;
     const int m = t->m;
-    memset(t->skip, 0, (size_t)t->mcap);
-    for (int i = 0; i < t->mcap; ++i) t->dw[i] = 1.0;     /* new reference framework: the current basis */
+    for (int i = 0; i < t->mcap; ++i) { t->skip[i] &= 2; t->dw[i] = 1.0; }     /* bit 1 (mark_dead) stays; new devex reference framework: the current basis */
     int stall = 0;
     double last_obj = -INFINITY;
     const double *d = t->D + (size_t)t->mcap * ld;
@@ -468,7 +489,7 @@ static int dual_simplex(dict_t *t, double cutoff)
         if (t->pivots >= t->max_pivots) return LP_ITERLIMIT;
         if (t->pivots - checked_at >= 512) {   /* a long solve never reaches the verification at an optimum: verify on the way */
             checked_at = t->pivots;
-            if (check_residual(t) > ORC_RESID_TOL) { refactor(t); memset(t->skip, 0, (size_t)t->mcap); continue; }
+            if (check_residual(t) > ORC_RESID_TOL) { refactor(t); for (int i = 0; i < t->mcap; ++i) t->skip[i] &= 2; continue; }
         }
         const double cur = objective(t);
         if (cur > last_obj + 1e-12 * fmax(1.0, fabs(cur))) { stall = 0; last_obj = cur; } else stall++;
@@ -487,7 +508,7 @@ static int dual_simplex(dict_t *t, double cutoff)
         }
         if (r < 0) {
             checked_at = t->pivots;
-            if (check_residual(t) > ORC_RESID_TOL) { refactor(t); memset(t->skip, 0, (size_t)t->mcap); continue; }
+            if (check_residual(t) > ORC_RESID_TOL) { refactor(t); for (int i = 0; i < t->mcap; ++i) t->skip[i] &= 2; continue; }
             return LP_OPTIMAL;
         }
         if (bland) r = rb;
@@ -524,13 +545,13 @@ static int dual_simplex(dict_t *t, double cutoff)
             if (r0 < rmin) rmin = r0;
         }
         if (!any) {
-            if (viol <= ORC_PTOL_SKIP) { t->skip[r] = 1; continue; }
+            if (viol <= ORC_PTOL_SKIP) { t->skip[r] |= 1; continue; }
             if (t->pivots > checked_at && viol <= 1e-3) {
                 /* a SMALL violation without an eligible entry may be accumulated error (a degenerate basic variable
                  * drifting off its bound) rather than infeasibility: if the dictionary's discrepancy against the original
                  * rows is of the violation's size, re-derive it before believing the row */
                 checked_at = t->pivots;
-                if (check_residual(t) > 0.1 * viol) { refactor(t); memset(t->skip, 0, (size_t)t->mcap); continue; }
+                if (check_residual(t) > 0.1 * viol) { refactor(t); for (int i = 0; i < t->mcap; ++i) t->skip[i] &= 2; continue; }
             }
             return LP_INFEASIBLE;
         }
@@ -1075,6 +1096,7 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
         t->gcost = dalloc(n); t->vcur = dalloc(n); t->Pv = dalloc(n);
     }
     for (int i = 0; i < t->mcap; ++i) { t->lo[n + i] = 0; t->hi[n + i] = INFINITY; }
+    mark_dead(t, m, Pq == NULL);
     reset_dictionary(t);
     for (int c = 0; c < n; ++c) place(t, c);
     refresh(t);
