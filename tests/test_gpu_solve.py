@@ -374,3 +374,43 @@ def test_closed_loop_receding_horizon_matches_highs_every_step():
         x = np.array([x_next[0, 0]])
     assert sorted(ctrl.sim_log.keys()) == list(range(steps))
     assert 49.0 <= x[0] <= 66.0                                           # the thermostat band held (softly) over the run
+
+
+def test_never_binding_rows_do_not_change_the_answer():
+    """rows whose largest activity under the root bounds is below their right-hand side are not maintained by the pivots
+    (s_mark_dead / oracle mark_dead): the same batch with the elimination switched off (solver option reserved bit 4) must
+    give the same statuses and objectives, and a batch in which most rows are of that kind must still match HiGHS"""
+    from scipy.optimize import milp, LinearConstraint, Bounds
+    wl = syn.make_workload("cfg3", batch=96)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    m = gpu.GpuModel([ag["mats"]], d)
+    cost = host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"])
+    outs = []
+    for flag in (0, 16):
+        p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost, max_nodes=2000, gap_rel=1e-4, reserved=flag)
+        outs.append(p.solve(ag["x0"], ag["omega"]))
+        p.close()
+    a, b = outs
+    assert np.array_equal(a["status"], b["status"])
+    fin = np.isfinite(b["obj"])
+    assert fin.sum() >= 90
+    assert np.all(np.abs(a["obj"][fin] - b["obj"][fin]) <= 2e-4 * np.maximum(1.0, np.abs(b["obj"][fin])))     # both within the 1e-4 gap
+    # how many rows the rule removes on this shape (numpy restatement of the rule on the tightened, un-scaled rows)
+    sf = cn.standard_form(tighten_np.tighten(ag["mats"], d, nu_l=d["nu_l"]), ag["atoms"], wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
+    G, lb, ub = sf["G"], sf["lb"], sf["ub"]
+    pos, neg = np.maximum(G, 0), np.minimum(G, 0)
+    with np.errstate(invalid="ignore"):
+        act = np.where(pos > 0, pos * ub, 0).sum(1) + np.where(neg < 0, neg * lb, 0).sum(1)
+    h0 = cn.rhs(sf["evo"], ag["x0"][0], ag["omega"][0]).ravel()
+    assert (act <= h0 - 1e-7).mean() > 0.2
+    # and the answers are HiGHS's (original rows)
+    raw = cn.standard_form(ag["mats"], ag["atoms"], wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
+    for s in range(4):
+        h, q = cn.rhs(raw["evo"], ag["x0"][s], ag["omega"][s]), cn.lin_cost(raw["cost"], ag["x0"][s], ag["omega"][s])
+        r = cn.cost_const(raw["cost"]["const_terms"], ag["x0"][s], ag["omega"][s])
+        ref = milp(q, constraints=LinearConstraint(raw["G"], -np.inf, h), integrality=raw["is_bin"].astype(int),
+                   bounds=Bounds(raw["lb"], raw["ub"]), options=dict(mip_rel_gap=1e-6))
+        if a["status"][s] == 0 and ref.status == 0:
+            assert abs(a["obj"][s] - (ref.fun + r)) <= 2e-4 * max(1.0, abs(ref.fun + r)), (s, a["obj"][s], ref.fun + r)
+    m.close()
