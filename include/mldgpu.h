@@ -65,7 +65,10 @@ typedef struct {
     int32_t n_slots;       /* solver slots = persistent workgroups (0 = auto: what is resident at once, one per CU) */
     int32_t mir_per_round; /* complemented mixed-integer rounding cuts on the original rows per cut round
                               (default -1 = max(20, binaries / 10); 0 = off) */
-    int32_t reserved;
+    int32_t reserved;      /* diagnostics, default 0.  bit0 solver trace (builds with -DMLD_TRACE only), bit1 refactor at every
+                              verification, bit2 never refactor, bit3 no longest-first work queue, bit4 keep maintaining the rows
+                              that cannot bind under the root bounds, bit5 Gomory cuts one at a time (A/B of the wave-parallel
+                              round).  Results are the same up to rounding with every bit; only speed and traces change. */
 } mld_opts;
 
 /* Linear cost in tiled horizon form (the Python layer parses the reference's string-keyed atoms,
