@@ -10,6 +10,10 @@ model = gpu.GpuModel([a['mats'] for a in agents], d)
 cost = host.stack_costs([host.cost_from_atoms(a['atoms'], d, N_p, N_t) for a in agents])
 configs = [dict(), dict(cut_rounds=4), dict(cut_rounds=6), dict(cut_rounds=12), dict(mir_per_round=10), dict(mir_per_round=40),
            dict(cuts_per_round=20), dict(cuts_per_round=80, max_cuts=300), dict(cut_rounds=6, mir_per_round=30)]
+if len(sys.argv) > 2 and sys.argv[2] == "wide":     # more Gomory cuts (cheap since they are derived eight at a time), fewer rounding cuts
+    configs = [dict(), dict(cuts_per_round=80, max_cuts=300), dict(cuts_per_round=80, max_cuts=300, mir_per_round=10),
+               dict(cuts_per_round=80, max_cuts=300, mir_per_round=15), dict(cuts_per_round=120, max_cuts=400),
+               dict(cuts_per_round=120, max_cuts=400, mir_per_round=10), dict(cuts_per_round=80, max_cuts=300, cut_rounds=10)]
 for kw in configs:
     prob = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=1e-2, max_nodes=400, max_pivots=20000, **kw)
     prob.upload(x0, om, midx); prob.solve_resident(); st = prob.solve_resident()
