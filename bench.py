@@ -247,6 +247,12 @@ def main():
         result["roofline_condense"] = {"kernel": "k_condense_model+k_condense_flat", "bound": "hbm", "achieved": round(ach, 1),
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                        "bytes_per_model": int(bytes_cond), "models": args.agents, "kernel_ms": round(ms, 4)}
+        try:        # HBM bytes of the two condensing launches from the same PMC passes (FETCH + WRITE, per launch of each kernel)
+            allc = json.load(open(pmc)).get("all", {})
+            kb = sum(allc.get(c, {}).get(k, {}).get("kb_per_launch", 0.0) for c in ("FETCH_SIZE", "WRITE_SIZE") for k in ("k_condense_model", "k_condense_flat"))
+            result["roofline_condense"]["traffic"] = kb * 1024.0 if kb > 0 else None
+        except Exception:
+            result["roofline_condense"]["traffic"] = None
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:    # CPU leg: rank 0 at N=1 only
             result["cpu_baseline"] = cpu_baseline(agents, N_p, N_t, x0, om, midx, args.cpu_sample, args.mip_gap, args.node_limit, args.pivot_limit)
         else:
