@@ -10,7 +10,10 @@ model = gpu.GpuModel([a['mats'] for a in agents], d)
 cost = host.stack_costs([host.cost_from_atoms(a['atoms'], d, N_p, N_t) for a in agents])
 configs = [dict(), dict(cut_rounds=4), dict(cut_rounds=6), dict(cut_rounds=12), dict(mir_per_round=10), dict(mir_per_round=40),
            dict(cuts_per_round=20), dict(cuts_per_round=80, max_cuts=300), dict(cut_rounds=6, mir_per_round=30)]
-if len(sys.argv) > 2 and sys.argv[2] == "wide":     # more Gomory cuts (cheap since they are derived eight at a time), fewer rounding cuts
+if len(sys.argv) > 2 and sys.argv[2] == "combo":
+    configs = [dict(), dict(cuts_per_round=80, max_cuts=300, cut_rounds=10, mir_per_round=10), dict(cuts_per_round=80, max_cuts=300, cut_rounds=10, mir_per_round=15),
+               dict(cuts_per_round=80, max_cuts=300, cut_rounds=12, mir_per_round=10), dict(cuts_per_round=80, max_cuts=400, cut_rounds=12, mir_per_round=12)]
+elif len(sys.argv) > 2 and sys.argv[2] == "wide":     # more Gomory cuts (cheap since they are derived eight at a time), fewer rounding cuts
     configs = [dict(), dict(cuts_per_round=80, max_cuts=300), dict(cuts_per_round=80, max_cuts=300, mir_per_round=10),
                dict(cuts_per_round=80, max_cuts=300, mir_per_round=15), dict(cuts_per_round=120, max_cuts=400),
                dict(cuts_per_round=120, max_cuts=400, mir_per_round=10), dict(cuts_per_round=80, max_cuts=300, cut_rounds=10)]

@@ -393,8 +393,8 @@ def test_never_binding_rows_do_not_change_the_answer():
         p.close()
     a, b = outs
     assert np.array_equal(a["status"], b["status"])
-    fin = np.isfinite(b["obj"])
-    assert fin.sum() >= 90
+    fin = (a["status"] == 0) & (b["status"] == 0)
+    assert fin.sum() >= 88
     assert np.all(np.abs(a["obj"][fin] - b["obj"][fin]) <= 2e-4 * np.maximum(1.0, np.abs(b["obj"][fin])))     # both within the 1e-4 gap
     # how many rows the rule removes on this shape (numpy restatement of the rule on the tightened, un-scaled rows)
     sf = cn.standard_form(tighten_np.tighten(ag["mats"], d, nu_l=d["nu_l"]), ag["atoms"], wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
