@@ -42,6 +42,9 @@
 #define ORC_INTTOL 1e-6
 #define ORC_COEF_ZERO 1e-9
 #define ORC_RESID_TOL 1e-6
+#ifndef ORC_PEN_DEFAULT
+#define ORC_PEN_DEFAULT 1
+#endif
 
 enum { ORC_OPTIMAL = 0, ORC_INFEASIBLE = 1, ORC_NODE_LIMIT = 2, ORC_NUMERICAL = 3, ORC_UNBOUNDED = 4 };
 enum { LP_OPTIMAL = 0, LP_INFEASIBLE = 1, LP_CUTOFF = 2, LP_ITERLIMIT = 3 };
@@ -1041,6 +1044,28 @@ static int mir_round(dict_t *t, int max_cuts)
     return added;
 }
 
+/* Driebeek (1966) / Tomlin penalties of a fractional basic binary in row r: lower bounds on the rise of the LP value when the
+ * variable is branched down (x <= 0) or up (x >= 1), from one dual ratio test on its dictionary row each -- the first
+ * dual simplex pivot of the child.  Every non-zero eligible entry takes part (no pivot tolerance: a smaller ratio only
+ * weakens the bound), so obj + penalty never exceeds the child's LP value. */
+static void penalties(const dict_t *t, int r, double *pd_out, double *pu_out)
+{
+    const int n = t->n;
+    const double *row = t->D + (size_t)r * t->ld, *d = t->D + (size_t)t->mcap * t->ld;
+    const double f = t->xB[r] - floor(t->xB[r]);
+    double rd = INFINITY, ru = INFINITY;
+    for (int c = 0; c < n; ++c) {
+        const int j = t->nonbasic[c];
+        if (t->lo[j] == t->hi[j]) continue;
+        const double a = row[c];
+        if (fabs(a) <= 1e-9) continue;
+        const double da = fmax(t->at_upper[c] ? -d[c] : d[c], 0.0), ratio = da / fabs(a);
+        if (t->at_upper[c] ? a < 0 : a > 0) { if (ratio < rd) rd = ratio; } else { if (ratio < ru) ru = ratio; }
+    }
+    *pd_out = isfinite(rd) ? rd * f : INFINITY;
+    *pu_out = isfinite(ru) ? ru * (1.0 - f) : INFINITY;
+}
+
 static double gtol(const orc_opts *o, double v) { return fmax(o->gap_abs, o->gap_rel * fabs(v)); }
 
 int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double *G, const double *h, const double *lb_in,
@@ -1168,11 +1193,13 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
         const double root_bound = st->root_bound;
         int nodes = 0, limit = 0, pass = 0, rescue = 0, node_budget = o->max_nodes;
         int phase = PH_IDS, rins_rounds = 0, nfix = 0, unbounded = 0;
-        const int ids_cap = o->max_nodes / 4 > 16 ? o->max_nodes / 4 : 16;
+        const int ids_cap = o->max_nodes / 8 > 16 ? o->max_nodes / 8 : 16;
         const double dive_tol = 1e-2 * fmax(1.0, fabs(root_bound));
         double *xroot = dalloc(nb + 1), *fx_lo = dalloc(nb + 1), *fx_hi = dalloc(nb + 1);
         int *fx_j = (int *)calloc(nb + 1, sizeof(int));
         double T = root_bound + fmax(1e-7 * fmax(1.0, fabs(root_bound)), gtol(o, root_bound));
+        const int pen_mode = getenv("ORC_PEN") ? atoi(getenv("ORC_PEN")) : ORC_PEN_DEFAULT;   /* 0: first fractional binary in index order (A/B) */
+        double lbg = root_bound;      /* proven global lower bound: raised by every exhaustive pass */
         status = ORC_NODE_LIMIT;
         for (;;) {
             int depth = 0;
@@ -1195,6 +1222,7 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                 /* ---- evaluate the current node */
                 nodes++;
                 int branch_j = -1; double branch_x = 0;
+                int force_first = -1, second_done = 0;      /* penalty branching: preferred side, other side already excluded */
                 const double inc_cut = have ? best - gtol(o, best) : INFINITY;
                 const double cut = fmin(T, inc_cut);
                 double node_obj = INFINITY;
@@ -1240,12 +1268,42 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                                 const int j = bins[k];
                                 if (fabs(xs[j] - rint(xs[j])) > ORC_INTTOL && xs[j] > bv) { bv = xs[j]; branch_j = j; branch_x = xs[j]; }
                             }
+                        } else if (pen_mode && !t->P) {
+                            /* penalty branching: the fractional binary with the largest product of up / down penalties (first index on
+                             * ties); a side whose penalty lifts the bound over the cutoff is excluded without a node of its own, and the
+                             * node is pruned when some variable has both sides excluded */
+                            const double eps = 1e-6 * fmax(1.0, fabs(obj));
+                            double bscore = -1.0; int bforced = 0;
+                            for (int k = 0; k < nb && !pruned; ++k) {
+                                const int j = bins[k];
+                                if (fabs(xs[j] - rint(xs[j])) <= ORC_INTTOL) continue;
+                                const int w = t->where[j];
+                                if (w >= 0) continue;       /* (a fractional binary is basic) */
+                                double pd, pu;
+                                penalties(t, -1 - w, &pd, &pu);
+                                const int xd = obj + pd > cut, xu = obj + pu > cut;
+                                if (xd && xu) {
+                                    const double b = obj + fmin(pd, pu);
+                                    pruned = 1; branch_j = -1;
+                                    if (b <= inc_cut && b < t_next) t_next = b;
+                                    break;
+                                }
+                                if (xd || xu) {
+                                    const double b = obj + (xd ? pd : pu);
+                                    if (b <= inc_cut && b < t_next) t_next = b;
+                                    if (!bforced) { bforced = 1; branch_j = j; branch_x = xs[j]; force_first = xd ? 1 : 0; second_done = 1; }
+                                    continue;
+                                }
+                                if (bforced) continue;
+                                const double sc = fmax(fmin(pd, 1e30), eps) * fmax(fmin(pu, 1e30), eps);
+                                if (sc > bscore) { bscore = sc; branch_j = j; branch_x = xs[j]; force_first = (pd == pu) ? -1 : (pd < pu ? 0 : 1); second_done = 0; }
+                            }
                         } else
                         for (int k = 0; k < nb; ++k) {
                             const int j = bins[k];
                             if (fabs(xs[j] - rint(xs[j])) > ORC_INTTOL) { branch_j = j; branch_x = xs[j]; break; }
                         }
-                        if (branch_j < 0) {
+                        if (branch_j < 0 && !pruned) {
                             /* leaf: fix every binary at its rounded value, re-solve, verify, restore */
                             int ns = 0;
                             for (int k = 0; k < nb; ++k) {
@@ -1290,7 +1348,7 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                         }
                     }
                 }
-                if (have && (rescue || unbounded || best <= root_bound + gtol(o, best))) { finished = 1; }
+                if (have && (rescue || unbounded || best <= lbg + gtol(o, best))) { finished = 1; }
                 if (nodes >= ((phase == PH_IDS && !have && !rescue) ? ids_cap : node_budget)) limit = 1;
                 if (phase == PH_DIVE && !limit && !finished) {
                     /* no backtracking: the dive ends at its first leaf, or when the node is infeasible */
@@ -1317,8 +1375,8 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                     }
                 }
                 if (branch_j >= 0 && !limit && !finished && !dive_end) {
-                    const double first = branch_x >= 0.5 ? 1.0 : 0.0;
-                    stk_j[depth] = branch_j; stk_first[depth] = first; stk_second[depth] = 0; depth++;
+                    const double first = force_first >= 0 ? (double)force_first : (branch_x >= 0.5 ? 1.0 : 0.0);
+                    stk_j[depth] = branch_j; stk_first[depth] = first; stk_second[depth] = (unsigned char)second_done; depth++;
                     set_bounds(t, branch_j, first, first);
                     continue; /* evaluate the child */
                 }
@@ -1367,12 +1425,14 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                 status = have ? (rescue ? ORC_NODE_LIMIT : ORC_OPTIMAL) : ORC_INFEASIBLE;
                 break;
             }
+            if (t_next > lbg) lbg = t_next;
             if (have) T = INFINITY;
             else T = fmax(t_next + 1e-9 * fmax(1.0, fabs(t_next)), T + ldexp(2.5e-4, 2 * pass) * fmax(1.0, fabs(T)));
         }
         free(xroot); free(fx_lo); free(fx_hi); free(fx_j);
         st->nodes = nodes;
-        st->lower_bound = status == ORC_OPTIMAL ? best : root_bound;
+        /* every way of ending OPTIMAL has closed all nodes below best - gtol; otherwise the bound is what exhaustive passes proved */
+        st->lower_bound = status == ORC_OPTIMAL ? fmin(best, fmax(lbg, best - gtol(o, best))) : lbg;
     }
 done:
     if (Ps) { free(Ps); free(t->Y); free(t->PY); free(t->Hm); free(t->cm); free(t->wm); free(t->gcost); free(t->vcur); free(t->Pv); }

@@ -3,7 +3,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'oracle')
 import bench
 import condense_np as cn, orc, tighten_np
 i = int(sys.argv[1])
-agents, N_p, N_t, x0, om, midx = bench.make_shard(64, 8, 0)
+agents, N_p, N_t, x0, om, midx = bench.make_shard(64, max(8, i // 64 + 1), 0)
 a = int(midx[i]); ag = agents[a]; d = ag["dims"]
 tm = tighten_np.tighten(ag["mats"], d, nu_l=d["nu_l"])
 sf = cn.standard_form(tm, ag["atoms"], N_p, N_t, nu_l=d["nu_l"])
