@@ -170,6 +170,20 @@ int mld_solve_resident(mld_problem_t *, mld_stats *stats_out);
 int mld_download_results(mld_problem_t *, double *v_out, double *obj_out, int32_t *status_out,
                          double *lower_bound_out, int32_t *nodes_out, int32_t *pivots_out);
 
+/* Limits and tolerances of an existing problem (gap_abs, gap_rel, max_nodes, max_pivots, cut_rounds, cuts_per_round,
+ * mir_per_round, reserved; negative cut fields keep the current value).  The reference passes MIPGap / NodeLimit / TimeLimit as
+ * per-call **solver_kwargs of solve() (controllers/controller_base.py:491-512): they must not need a rebuild.  max_cuts,
+ * n_slots and presolve shape the workspace / the tightened model and are ignored here. */
+int mld_problem_set_opts(mld_problem_t *, const mld_opts *opts);
+
+/* Receding horizon on device -- the plant update the reference performs after every solve, ControllerBase.sim_step_k ->
+ * MldModel.lsim_k (controllers/controller_base.py:229-253, models/mld_model.py:647-699): for every instance of the uploaded
+ * batch  x0 <- A x0 + B1 u + B2 delta + B3 z + B4 omega_0 + b5  with (u, delta, z) the step-0 slice of the last solution, and the
+ * disturbance forecast moved on by one step (the first step re-enters at the end of the horizon).  The next
+ * mld_solve_resident then solves the NEXT MPC step without any host traffic.  mld_download_inputs reads the current inputs. */
+int mld_advance_batch(mld_problem_t *);
+int mld_download_inputs(mld_problem_t *, double *x0, double *omega);
+
 /* Per-instance telemetry of the last solve: time spent inside the solve kernel (device wall clock, ns) and
  * the number of dictionary rows the rank-1 updates touched (x *row_bytes x 2 = bytes streamed by pivots). */
 int mld_download_telemetry(mld_problem_t *, int64_t *latency_ns, int64_t *rows_updated, int64_t *row_bytes);
@@ -189,6 +203,11 @@ int mld_rhs_batch(mld_problem_t *, int batch, int scenarios, const int32_t *mode
 int mld_comm_unique_id(uint8_t id[MLD_COMM_ID_BYTES]);
 int mld_comm_init(int n_ranks, int rank, const uint8_t id[MLD_COMM_ID_BYTES]);
 int mld_gather(const double *send, int count, double *recv);
+/* The result gather of the path straight from the device buffers of the last solve (no host staging of the send side): per
+ * instance 2 + nv doubles = (objective, status, step-0 slice [u0; delta0; z0; mu0] -- what `variables_k` hands the caller,
+ * controllers/components/variables.py:75-85); every rank contributes its whole batch (equal on all ranks); recv (host) holds
+ * n_ranks x batch x (2 + nv), rank-major. */
+int mld_gather_results(mld_problem_t *, double *recv, int *width_out);
 int mld_comm_destroy(void);
 
 #ifdef __cplusplus

@@ -39,6 +39,7 @@
 #define ORC_DTOL 1e-9
 #define ORC_PIV_ABS 1e-7
 #define ORC_PIV_REL 1e-7
+#define ORC_PIV_TINY 1e-5
 #define ORC_INTTOL 1e-6
 #define ORC_COEF_ZERO 1e-9
 #define ORC_RESID_TOL 1e-6
@@ -515,7 +516,14 @@ static int dual_simplex(dict_t *t, double cutoff)
             return LP_OPTIMAL;
         }
         if (bland) r = rb;
-        if (cur >= cutoff) return LP_CUTOFF;
+        if (cur >= cutoff) {
+            /* a cutoff is a claim about the bound: verify the dictionary first if it has moved since the last check */
+            if (t->pivots - checked_at >= 64) {
+                checked_at = t->pivots;
+                if (check_residual(t) > ORC_RESID_TOL) { refactor(t); for (int i = 0; i < t->mcap; ++i) t->skip[i] &= 2; continue; }
+            }
+            return LP_CUTOFF;
+        }
         const int jr = t->basic[r];
         const double vlo = t->lo[jr] - t->xB[r], vhi = t->xB[r] - t->hi[jr];
         const int below = vlo > vhi;
@@ -570,6 +578,12 @@ static int dual_simplex(dict_t *t, double cutoff)
             if (bland) {
                 if (r0 <= rmin * (1 + 1e-12) + 1e-300 && j < idbest) { idbest = j; cbest = c; }
             } else if (r0 <= tmax && fabs(a) > abest) { abest = fabs(a); cbest = c; }
+        }
+        if (fabs(row[cbest]) < ORC_PIV_TINY && viol <= ORC_PTOL_SKIP) {
+            /* a violation within the skip tolerance whose only pivots are tiny: the dual step d_q / |a_q| would be huge and
+             * the entries the ratio test ignored (|a| <= ptol) would carry it into their reduced costs -- dual feasibility,
+             * and with it the bound, is lost (seen: violation 5e-8, pivot 1.7e-7, step 3e9).  The row counts as satisfied. */
+            t->skip[r] |= 1; continue;
         }
         pivot(t, r, cbest, below ? t->lo[jr] : t->hi[jr]);
     }
@@ -1375,7 +1389,8 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                     }
                 }
                 if (branch_j >= 0 && !limit && !finished && !dive_end) {
-                    const double first = force_first >= 0 ? (double)force_first : (branch_x >= 0.5 ? 1.0 : 0.0);
+                    double first = force_first >= 0 ? (double)force_first : (branch_x >= 0.5 ? 1.0 : 0.0);
+                    if (have && phase == PH_FINAL && !second_done) first = x_out[branch_j];     /* guided (Danna et al. 2005): towards the incumbent first */
                     stk_j[depth] = branch_j; stk_first[depth] = first; stk_second[depth] = (unsigned char)second_done; depth++;
                     set_bounds(t, branch_j, first, first);
                     continue; /* evaluate the child */
@@ -1400,12 +1415,12 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
             }
             if (phase == PH_DIVE) {
                 limit = nodes >= o->max_nodes;
-                if (have && !limit) { phase = PH_RINS; node_budget = nodes + (o->max_nodes * 3) / 8 < o->max_nodes ? nodes + (o->max_nodes * 3) / 8 : o->max_nodes; continue; }
+                if (have && !limit) { phase = PH_RINS; node_budget = nodes + o->max_nodes / 4 < o->max_nodes ? nodes + o->max_nodes / 4 : o->max_nodes; continue; }
                 if (!have && !limit) { phase = PH_FINAL; node_budget = o->max_nodes; continue; }
             } else if (phase == PH_RINS) {
                 limit = nodes >= o->max_nodes;
                 if (!limit) {
-                    if (best < best_at_start && rins_rounds < 2) { node_budget = nodes + (o->max_nodes * 3) / 8 < o->max_nodes ? nodes + (o->max_nodes * 3) / 8 : o->max_nodes; continue; }
+                    if (best < best_at_start && rins_rounds < 2) { node_budget = nodes + o->max_nodes / 4 < o->max_nodes ? nodes + o->max_nodes / 4 : o->max_nodes; continue; }
                     phase = PH_FINAL; node_budget = o->max_nodes; continue;
                 }
             }
@@ -1466,4 +1481,31 @@ int orc_enumerate_milp(int n, int m, const double *q, const double *G, const dou
     *obj_out = best;
     free(l); free(u); free(x); free(nob);
     return isfinite(best) ? ORC_OPTIMAL : ORC_INFEASIBLE;
+}
+
+/* Batch of independent instances over all host cores (OpenMP, dynamic schedule: the solves differ by orders of magnitude) --
+ * the CPU baseline leg of bench.py ("OpenMP over instances on all host cores").  Instance i uses q[i], G[i], h[i];
+ * bounds and the binary mask are shared.  threads <= 0: all cores OpenMP gives this process. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int orc_solve_milp_batch(int n_inst, int n, int m, const double *const *q, const double *const *G, const double *const *h,
+                         const double *lb, const double *ub, const unsigned char *is_bin, const orc_opts *o, int threads,
+                         double *obj_out, int *status_out, int *nodes_out, int *pivots_out, double *lb_out)
+{
+    int used = 1;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+    used = threads;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+    for (int i = 0; i < n_inst; ++i) {
+        double *x = (double *)calloc((size_t)n + 1, sizeof(double));
+        orc_stats st;
+        double obj;
+        status_out[i] = orc_solve_milp(n, m, q[i], G[i], h[i], lb, ub, is_bin, o, x, &obj, &st);
+        obj_out[i] = obj; nodes_out[i] = st.nodes; pivots_out[i] = st.pivots; lb_out[i] = st.lower_bound;
+        free(x);
+    }
+    return used;
 }

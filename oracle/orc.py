@@ -80,6 +80,34 @@ def solve_milp(q, G, h, lb, ub, is_bin, **kw):
                 root_bound=st.root_bound, lower_bound=st.lower_bound)
 
 
+def solve_milp_batch(qs, Gs, hs, lb, ub, is_bin, threads=0, **kw):
+    """independent instances (q_i, G_i, h_i) over `threads` host cores (0 = all) with OpenMP: orc_solve_milp_batch.
+    Gs may repeat the same array object for instances that share a model.  Returns (dict of arrays, threads used)."""
+    n_inst = len(qs)
+    qs = [np.ascontiguousarray(a, np.float64) for a in qs]
+    hs = [np.ascontiguousarray(a, np.float64) for a in hs]
+    keep = {}
+    Gc = []
+    for a in Gs:
+        if id(a) not in keep:
+            keep[id(a)] = np.ascontiguousarray(a, np.float64)
+        Gc.append(keep[id(a)])
+    m, n = Gc[0].shape
+    lb = np.ascontiguousarray(lb, np.float64)
+    ub = np.ascontiguousarray(ub, np.float64)
+    ib = np.ascontiguousarray(is_bin, np.uint8)
+    PP = C.POINTER(C.c_double) * n_inst
+    qp, Gp, hp = PP(*[_p(a) for a in qs]), PP(*[_p(a) for a in Gc]), PP(*[_p(a) for a in hs])
+    obj, lbd = np.zeros(n_inst), np.zeros(n_inst)
+    st, nd, pv = np.zeros(n_inst, np.int32), np.zeros(n_inst, np.int32), np.zeros(n_inst, np.int32)
+    o = make_opts(**kw)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    lib().orc_solve_milp_batch.restype = C.c_int
+    used = lib().orc_solve_milp_batch(n_inst, n, m, qp, Gp, hp, _p(lb), _p(ub), ib.ctypes.data_as(C.POINTER(C.c_ubyte)), C.byref(o),
+                                      int(threads), _p(obj), ip(st), ip(nd), ip(pv), _p(lbd))
+    return dict(obj=obj, status=st, nodes=nd, pivots=pv, lower_bound=lbd), used
+
+
 def solve_miqp(P, q, G, h, lb, ub, is_bin, **kw):
     """min 1/2 x'Px + q'x over the mixed-integer polytope (P symmetric PSD)"""
     P = np.ascontiguousarray(P, np.float64)

@@ -528,12 +528,15 @@ class MpcController(object):
                     remap[key] = val
                 elif key not in ("TimeLimit",):
                     raise TypeError("unsupported solver option %r" % key)
-            if remap and remap != getattr(self, "_last_remap", None):
-                self._solver_opts.update(remap)
-                self._last_remap = remap
-                self._problem.close()
-                self._problem = None
-                self.build(sense="min" if self._sense > 0 else "max")
+            # Gurobi-style kwargs are PER CALL, as in the reference (they go straight to Problem.solve, controller_base.py:509): the
+            # limits of the existing problem are set without a rebuild and fall back to the constructor's options afterwards
+            names = dict(MIPGap="gap_rel", NodeLimit="max_nodes", IterationLimit="max_pivots")
+            ctor = gpu.make_opts(**self._solver_opts)
+            eff = {k2: getattr(ctor, k2) for k2 in ("gap_rel", "max_nodes", "max_pivots", "gap_abs")}
+            eff.update({names[k2]: v2 for k2, v2 in remap.items()})
+            cur = self._problem.opts
+            if any(getattr(cur, k2) != type(getattr(cur, k2))(v2) for k2, v2 in eff.items()):
+                self._problem.set_opts(**eff)
             try:
                 cols = rows = None
                 if getattr(self, "_other_constraints", None):

@@ -215,6 +215,29 @@ class GpuProblem(object):
                                                        cr.ctypes.data_as(C.POINTER(C.c_int32)) if cr is not None else None))
         return n_cols
 
+    def set_opts(self, **opts):
+        """limits / tolerances of the existing problem (mld_problem_set_opts): MIPGap, NodeLimit, IterationLimit, gap_abs, cut
+        rounds, reserved -- no rebuild, like the per-call solver kwargs of the reference's solve()"""
+        alias = dict(MIPGap="gap_rel", NodeLimit="max_nodes", IterationLimit="max_pivots")
+        for k, v in opts.items():
+            k = alias.get(k, k)
+            if k in ("max_cuts", "n_slots", "presolve") or not hasattr(self.opts, k):
+                raise TypeError("option %r cannot be changed on an existing problem" % k)
+            setattr(self.opts, k, type(getattr(self.opts, k))(v))
+        check(_lib.load().mld_problem_set_opts(self._h, C.byref(self.opts)))
+
+    def advance(self):
+        """receding horizon on device (mld_advance_batch): x0 <- plant update with the step-0 slice of the last solution,
+        disturbance forecast moved on by one step; the next solve_resident() is the next MPC step"""
+        check(_lib.load().mld_advance_batch(self._h))
+
+    def inputs(self):
+        """current (x0, omega) of the resident batch"""
+        d = self.model.dims
+        x0, om = np.zeros((self.batch, d["nx"])), np.zeros((self.batch, self.nW))
+        check(_lib.load().mld_download_inputs(self._h, _lib.dptr(x0) if d["nx"] else None, _lib.dptr(om) if self.nW else None))
+        return x0, om
+
     def solve_resident(self):
         st = _lib.Stats()
         check(_lib.load().mld_solve_resident(self._h, C.byref(st)))

@@ -1,0 +1,99 @@
+"""GPU parity on the BENCHMARKED workload (bench.make_shard, bench options) against optima from a solver nobody here wrote.
+
+tests/golden/solve_cfg4_bench.npz / solve_cfg3.npz hold scipy-HiGHS optimal objectives (mip_rel_gap = 0, ORIGINAL rows; made by
+oracle/gen_solve_golden.py) of the seeded instances.  What the reference's backend call guarantees and is checked here
+(controllers/controller_base.py:509, :533-535; MIPGap semantics micro_grid_control_simulation.py:232): the returned point is
+feasible so its objective is never below the optimum, a reported lower bound is never above it, an OPTIMAL status means the
+objective is within the requested gap of the optimum, and the node-limited tail still returns usable control actions.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import bench
+from pyhybridcontrol_amd import gpu, host, synthetic as syn
+from test_gpu_solve import check_solution
+
+pytestmark = pytest.mark.gpu
+
+GDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GAP, NODES, PIVOTS = 1e-2, 400, 20000          # bench.py defaults
+
+
+def _solve_shard(n_scen, **opts):
+    agents, N_p, N_t, x0, om, midx = bench.make_shard(64, n_scen, 0)
+    d = agents[0]["dims"]
+    model = gpu.GpuModel([a["mats"] for a in agents], d)
+    cost = host.stack_costs([host.cost_from_atoms(a["atoms"], d, N_p, N_t) for a in agents])
+    prob = gpu.GpuProblem(model, N_p, N_t, cost, **opts)
+    out = prob.solve(x0, om, midx)
+    prob.close(); model.close()
+    return agents, N_p, N_t, x0, om, midx, out
+
+
+def _check_against_optimum(out, opt, gap):
+    st, obj, lb = out["status"], out["obj"], out["lower_bound"]
+    scale = np.maximum(1e-9, np.abs(opt))
+    assert np.all((st == 0) | (st == 2)), np.unique(st)
+    assert np.all(np.isfinite(obj)), "every instance returns an incumbent"
+    assert np.all(obj >= opt - 1e-6 * scale), "a feasible point cannot beat the optimum: %g" % ((opt - obj) / scale).max()
+    assert np.all(lb <= opt + 1e-6 * scale), "reported lower bound above the optimum: %g" % ((lb - opt) / scale).max()
+    rel = (obj - opt) / scale
+    claimed = st == 0
+    assert np.all(obj[claimed] - opt[claimed] <= gap * np.abs(obj[claimed]) + 1e-6 * scale[claimed] + 1e-9), \
+        "OPTIMAL outside the gap: worst %g" % rel[claimed].max()
+    return rel
+
+
+def test_bench_workload_within_gap_of_highs_optimum():
+    """first 1024 instances of the bench shard, bench options: bounds bracket the HiGHS optimum, OPTIMAL means within MIPGap,
+    and the node-limited tail is capped"""
+    n_scen = 16
+    gold = np.load(os.path.join(GDIR, "solve_cfg4_bench.npz"))
+    assert np.all(gold["proven"][: n_scen * 64] == 1)
+    opt = gold["obj"][: n_scen * 64]
+    agents, N_p, N_t, x0, om, midx, out = _solve_shard(n_scen, gap_rel=GAP, max_nodes=NODES, max_pivots=PIVOTS)
+    rel = _check_against_optimum(out, opt, GAP)
+    within = float((rel <= GAP + 1e-9).mean())
+    proven = float((out["status"] == 0).mean())
+    print("bench parity: proven %.4f within-gap %.4f worst %.4f node-limited %d" % (proven, within, rel.max(), int((out["status"] == 2).sum())))
+    assert proven >= 0.985, proven                      # (round 1: 0.979)
+    assert within >= 0.995, within
+    assert rel.max() <= 0.10, "an incumbent more than 10 %% above the optimum: %g" % rel.max()
+    wl = dict(N_p=N_p, N_tilde=N_t)
+    for i in list(range(0, 1024, 37)) + list(np.where(out["status"] == 2)[0][:8]):      # certificates on the original rows
+        ag = dict(agents[int(midx[i])], x0=x0[i][None], omega=om[i][None])
+        check_solution(ag, wl, 0, out["v"][i], out["obj"][i])
+
+
+def test_bench_workload_exact_contract():
+    """north star: within 1e-6 of the CPU reference.  gap 1e-6 with a node limit high enough to prove: every proven instance
+    equals the HiGHS optimum to 1e-6 relative"""
+    n_scen = 4
+    gold = np.load(os.path.join(GDIR, "solve_cfg4_bench.npz"))
+    opt = gold["obj"][: n_scen * 64]
+    _, _, _, _, _, _, out = _solve_shard(n_scen, gap_rel=1e-6, max_nodes=20000, max_pivots=400000)
+    rel = _check_against_optimum(out, opt, 1e-6)
+    proven = out["status"] == 0
+    print("exact contract: proven %d of %d, worst |obj-opt|/|opt| over proven %.3g" % (proven.sum(), proven.size, np.abs(rel[proven]).max()))
+    assert proven.mean() >= 0.97, proven.mean()
+    assert np.abs(rel[proven]).max() <= 2e-6
+
+
+def test_cfg3_against_highs_optimum():
+    gold = np.load(os.path.join(GDIR, "solve_cfg3.npz"))
+    nb = int(gold["n_scen"])
+    wl = syn.make_workload("cfg3", batch=nb)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    m = gpu.GpuModel([ag["mats"]], d)
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"]),
+                       gap_rel=1e-6, max_nodes=20000, max_pivots=400000)
+    out = p.solve(ag["x0"], ag["omega"])
+    p.close(); m.close()
+    rel = _check_against_optimum(out, gold["obj"], 1e-6)
+    proven = out["status"] == 0
+    print("cfg3 exact: proven %d of %d" % (proven.sum(), nb))
+    assert proven.mean() >= 0.95, proven.mean()
+    assert np.abs(rel[proven]).max() <= 2e-6

@@ -52,3 +52,48 @@ def test_gather_sharded_world2_gloo(total):
     expect = np.stack([idx, idx ** 2, idx % 3], axis=1)
     for r in range(2):
         assert np.array_equal(res[r], expect)
+
+
+class _RdzvGather(object):
+    """all_gather(array) over the torch-free rendezvous -- stands in for the RCCL gather on CPU"""
+
+    def __init__(self, rdzv):
+        self.rdzv, self.world = rdzv, rdzv.world
+
+    def all_gather(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        return [np.frombuffer(b, dtype=np.float64).reshape(arr.shape) for b in self.rdzv.all_gather_bytes(arr.tobytes())]
+
+
+def _rdzv_worker(rank, world, port, total, q):
+    from pyhybridcontrol_amd.batch import TcpRendezvous
+    rd = TcpRendezvous(rank=rank, world=world, addr="127.0.0.1", port=port, timeout=60.0)
+    uid = rd.broadcast(bytes(range(128)) if rank == 0 else b"", src=0)      # the 128 id bytes of mld_comm_unique_id
+    rd.barrier()
+    slowest = rd.all_max(10.0 + rank)
+    lo, hi = shard_range(total, rank, world)
+    idx = np.arange(lo, hi, dtype=np.float64)
+    full = gather_sharded(np.stack([idx, idx ** 2], axis=1), total, rank, world, _RdzvGather(rd))
+    rd.close()
+    q.put((rank, uid, slowest, full))
+
+
+def test_tcp_rendezvous_world3_without_torch():
+    """the launcher side channel of bench.py --gpus N: unique-id broadcast, barrier, max over ranks, uneven shards"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    world, total = 3, 10
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    idx = np.arange(total, dtype=np.float64)
+    for rank, uid, slowest, full in res:
+        assert uid == bytes(range(128))
+        assert slowest == 10.0 + world - 1
+        assert np.array_equal(full, np.stack([idx, idx ** 2], axis=1))
