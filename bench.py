@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--node-limit", type=int, default=800, help="per-instance node limit (stands in for the reference's TimeLimit)")
     ap.add_argument("--pivot-limit", type=int, default=40000, help="per-instance simplex iteration limit")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="instances timed with the CPU oracle on all cores (0 = skip)")
-    ap.add_argument("--exact-sample", type=int, default=2048, help="instances of the exact-gap leg (0 = skip)")
+    ap.add_argument("--exact-sample", type=int, default=-1, help="instances of the exact-gap leg (-1 = the whole shard, 0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank rehearsal on ONE GPU: every rank on device 0, gather over the TCP side channel")
     return ap.parse_args()
@@ -158,7 +158,7 @@ def cpu_baseline(agents, N_p, N_t, x0, om, midx, n_sample, gap, node_limit, pivo
 def exact_leg(prob, x0, om, midx, n_exact, args):
     """north star: "within 1e-6 objective of CPU reference".  The same problem at gap 1e-6 with a node limit high enough to
     prove, on the first n_exact instances of the shard; objectives checked against the committed HiGHS optima."""
-    n_exact = min(n_exact, x0.shape[0])
+    n_exact = x0.shape[0] if n_exact < 0 else min(n_exact, x0.shape[0])
     prob.set_opts(gap_rel=1e-6, max_nodes=20000, max_pivots=400000)
     prob.upload(x0[:n_exact], om[:n_exact], midx[:n_exact])
     t0 = time.perf_counter()
@@ -213,7 +213,7 @@ def main():
     prob = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit)
     n_local = x0.shape[0]
     exact = None
-    if world == 1 and args.exact_sample > 0:
+    if world == 1 and args.exact_sample != 0:
         exact = exact_leg(prob, x0, om, midx, args.exact_sample, args)
     prob.upload(x0, om, midx)                       # inputs resident in HBM before the timed region
     gatherer = None
@@ -313,6 +313,14 @@ def main():
                      "traffic_over_io_minimum": (round(traffic / io_bytes, 1) if traffic else None),
                      "kernel_ms": round(kernel_ms, 3), "measured_on": "last timed step (HIP events around k_solve on the launch stream)"},
     }
+    # K3 on the matrix cores: one [m0 x (nx + N nw)] . [(nx + N nw) x instances-of-the-model] GEMM per model
+    rhs_ms = float(np.mean([s["rhs_ms"] for s in stats]))
+    flops = 2.0 * prob.m * (d["nx"] + prob.nW) * n_local
+    result["mfma"] = {"kernel": "k_rhs_mfma (v_mfma_f64_16x16x4_f64)", "dtype": "f64", "flops_per_launch": int(flops), "ms": round(rhs_ms, 4),
+                      "tflops": round(flops / (rhs_ms * 1e-3) / 1e12, 3), "peak_tflops": 78.6,
+                      "frac_of_peak": round(flops / (rhs_ms * 1e-3) / 1e12 / 78.6, 5),
+                      "note": "fp64 matrix peak 78.6 TFLOP/s is AMD's MI355X figure (the guide lists 157.3 TFLOP/s for fp32 MFMA only); the launch moves "
+                              "%d MB of H + inputs + outputs, so it is bound by HBM / L2, not by the matrix cores" % int((64 * prob.m * (d["nx"] + prob.nW) * 8 + io_bytes) / 1e6)}
     if exact is not None:
         result["value_exact"] = exact["value_exact"]
         result["exact"] = exact

@@ -50,6 +50,12 @@ typedef struct {
 
 /* flags */
 #define MLD_CONDENSE_DEFAULT 0
+/* mld_opts.flags: the dense GEMMs of the path -- K3 constraint right-hand sides ([H_x | H_w] [x0 ; w], controllers/
+ * controller_base.py:446-450) and K4 quadratic cost pull-back (Gamma' W Gamma, controllers/components/objective_atoms.py:
+ * 321-331) -- run on the matrix cores in fp32 (v_mfma_f32_16x16x4_f32: inputs rounded to fp32, fp32 accumulate; relative
+ * error ~1e-6 of the largest term) instead of fp64 (v_mfma_f64_16x16x4_f64).  Arrays at the boundary stay `double`; the
+ * branch-and-cut itself always runs in fp64 and verifies every returned point against the original fp64 rows. */
+#define MLD_F32 1
 
 /* Solver options.  max_nodes / gap_rel / time-like limits mirror the Gurobi parameters the reference
  * forwards through **solver_kwargs (NodeLimit, MIPGap; micro_grid_control_simulation.py:232). */
@@ -65,10 +71,13 @@ typedef struct {
     int32_t n_slots;       /* solver slots = persistent workgroups (0 = auto: what is resident at once, one per CU) */
     int32_t mir_per_round; /* complemented mixed-integer rounding cuts on the original rows per cut round
                               (default -1 = max(20, binaries / 10); 0 = off) */
+    int32_t flags;         /* MLD_F32 (default 0, see below) */
     int32_t reserved;      /* diagnostics, default 0.  bit0 solver trace (builds with -DMLD_TRACE only), bit1 refactor at every
                               verification, bit2 never refactor, bit3 no longest-first work queue, bit4 keep maintaining the rows
                               that cannot bind under the root bounds, bit5 Gomory cuts one at a time (A/B of the wave-parallel
-                              round).  Results are the same up to rounding with every bit; only speed and traces change. */
+                              round).  Results are the same up to rounding with every bit; only speed and traces change.
+                              bit6 first-fractional branching instead of penalty branching, bit7 K3 / K4 on the vector ALUs (k_rhs, k_gemm)
+                              instead of the matrix cores. */
 } mld_opts;
 
 /* Linear cost in tiled horizon form (the Python layer parses the reference's string-keyed atoms,

@@ -17,6 +17,7 @@ EVO_NAMES = ("Phi_x", "Gamma_v", "Gamma_omega", "Gamma_5", "L_x", "L_v", "L_omeg
              "H_x", "H_v", "H_omega", "H_5")
 STATUS_NAMES = {0: "optimal", 1: "infeasible", 2: "node_limit", 3: "numerical", 4: "unbounded"}
 COMM_ID_BYTES = 128
+MLD_F32 = 1
 
 
 class MldGpuError(RuntimeError):
@@ -31,7 +32,7 @@ class Opts(C.Structure):
     _fields_ = [("gap_abs", C.c_double), ("gap_rel", C.c_double), ("max_nodes", C.c_int32),
                 ("max_pivots", C.c_int32), ("cut_rounds", C.c_int32), ("cuts_per_round", C.c_int32),
                 ("max_cuts", C.c_int32), ("presolve", C.c_int32), ("n_slots", C.c_int32), ("mir_per_round", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Cost(C.Structure):

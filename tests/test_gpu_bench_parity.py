@@ -18,7 +18,7 @@ from test_gpu_solve import check_solution
 pytestmark = pytest.mark.gpu
 
 GDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GAP, NODES, PIVOTS = 1e-2, 400, 20000          # bench.py defaults
+GAP, NODES, PIVOTS = 1e-2, 800, 40000          # bench.py defaults
 
 
 def _solve_shard(n_scen, **opts):
@@ -58,7 +58,7 @@ def test_bench_workload_within_gap_of_highs_optimum():
     within = float((rel <= GAP + 1e-9).mean())
     proven = float((out["status"] == 0).mean())
     print("bench parity: proven %.4f within-gap %.4f worst %.4f node-limited %d" % (proven, within, rel.max(), int((out["status"] == 2).sum())))
-    assert proven >= 0.985, proven                      # (round 1: 0.979)
+    assert proven >= 0.99, proven                       # (round 1: 0.979 at NodeLimit 400)
     assert within >= 0.995, within
     assert rel.max() <= 0.10, "an incumbent more than 10 %% above the optimum: %g" % rel.max()
     wl = dict(N_p=N_p, N_tilde=N_t)

@@ -1,0 +1,152 @@
+"""Closed loop on device and per-call limits: mld_advance_batch (the reference's sim_step_k / lsim_k plant update,
+controllers/controller_base.py:229-253, models/mld_model.py:647-699), mld_problem_set_opts (per-call solver kwargs,
+controller_base.py:491-512) and the deep-cut tight-gap regression against HiGHS."""
+import numpy as np
+import pytest
+
+import condense_np as cn
+from pyhybridcontrol_amd import gpu, host, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def test_advance_batch_is_the_plant_update_and_forecast_shift():
+    wl = syn.make_workload("cfg2", batch=6, n_agents=2)
+    d = wl["agents"][0]["dims"]
+    N = wl["N_tilde"]
+    m = gpu.GpuModel([a["mats"] for a in wl["agents"]], d)
+    cost = host.stack_costs([host.cost_from_atoms(a["atoms"], d, wl["N_p"], N) for a in wl["agents"]])
+    p = gpu.GpuProblem(m, wl["N_p"], N, cost, gap_rel=1e-2, max_nodes=400)
+    x0 = np.concatenate([a["x0"] for a in wl["agents"]])
+    om = np.concatenate([a["omega"] for a in wl["agents"]])
+    midx = np.repeat(np.arange(2), 6).astype(np.int32)
+    out = p.solve(x0, om, midx)
+    p.advance()
+    x1, om1 = p.inputs()
+    nv, nw = m.nv, d["nomega"]
+    for b in range(12):
+        mats = cn.pad_mats(wl["agents"][midx[b]]["mats"], cn.mld_dims(wl["agents"][midx[b]]["mats"]))
+        v0 = out["v"][b][:nv]
+        u, dl, z = v0[:d["nu"]], v0[d["nu"]:d["nu"] + d["ndelta"]], v0[d["nu"] + d["ndelta"]:d["nu"] + d["ndelta"] + d["nz"]]
+        w0 = om[b].reshape(N, nw)[0]
+        ref = mats["A"] @ x0[b] + mats["B1"] @ u + mats["B2"] @ dl + mats["B3"] @ z + mats["B4"] @ w0 + mats["b5"][:, 0]
+        assert np.allclose(x1[b], ref, rtol=1e-13, atol=1e-12), b
+        assert np.array_equal(om1[b].reshape(N, nw), np.roll(om[b].reshape(N, nw), -1, axis=0)), b
+    # the next step solves the advanced data: identical to uploading it explicitly
+    nxt = p.solve_resident(); got = p.download()
+    ref = p.solve(x1, om1, midx)
+    assert np.array_equal(got["status"], ref["status"]) and np.array_equal(got["obj"], ref["obj"])
+    assert nxt["n_optimal"] + nxt["n_node_limit"] == 12
+    p.close(); m.close()
+
+
+def test_set_opts_changes_limits_without_rebuild_and_back():
+    wl = syn.make_workload("cfg3", batch=16)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    m = gpu.GpuModel([ag["mats"]], d)
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"]), gap_rel=1e-2, max_nodes=400)
+    a = p.solve(ag["x0"], ag["omega"])
+    p.set_opts(max_nodes=1)
+    b = p.solve(ag["x0"], ag["omega"])
+    assert b["nodes"].max() <= 1 + 3 * p.n_bin + 10 and (b["status"] == 2).sum() > (a["status"] == 2).sum()
+    p.set_opts(MIPGap=1e-2, NodeLimit=400)
+    c = p.solve(ag["x0"], ag["omega"])
+    assert np.array_equal(a["obj"], c["obj"]) and np.array_equal(a["status"], c["status"])
+    with pytest.raises(TypeError):
+        p.set_opts(max_cuts=10)
+    p.close(); m.close()
+
+
+def test_solve_kwargs_are_per_call_and_keep_the_build_arguments():
+    """solve(k, MIPGap=...) used to rebuild with default build() arguments (soft constraints back on) and to persist"""
+    import pyhybridcontrol_amd as phc
+    model = phc.MldModel(A=[[0.9970371127900564]], B1=[[4.298192277481107]], B4=[[-179.73320827515]],
+                         b5=[[0.07407218024859108]], E=[[1], [-1]], F1=[[0], [0]], Psi=[[-1, 0], [0, -1]],
+                         f5=[[65.0], [-50.0]], nu_l=1, ts=900)
+    price = np.array([1, 3, 3, 1, 1.0])
+    om = [.004, .012, 0, .009, .002]
+    soft = phc.MpcController(model, N_p=4)
+    soft.set_std_obj_atoms(q_u=(price * 0.75).reshape(-1, 1), q_mu=[1e-3, 1e-3])     # violating the soft bounds is nearly free
+    soft.build()
+    cheap = soft.solve(0, x_k=[50.3], omega_tilde_k=om)
+    ctrl = phc.MpcController(model, N_p=4)
+    ctrl.set_std_obj_atoms(q_u=(price * 0.75).reshape(-1, 1), q_mu=[1e-3, 1e-3])
+    ctrl.build(disable_soft_constraints=True)
+    hard = ctrl.solve(0, x_k=[50.3], omega_tilde_k=om)
+    assert hard > cheap + 0.5, (hard, cheap)
+    again = ctrl.solve(0, MIPGap=1e-2, NodeLimit=50)
+    assert abs(hard - again) <= 1e-2 * abs(hard) + 1e-9, "solver kwargs must not re-enable the soft constraints"
+    assert np.all(np.abs(ctrl.v_N_tilde.reshape(5, 3)[:, 1:]) <= 1e-8)
+    assert ctrl._problem.opts.max_nodes == 50
+    ctrl.solve(0)
+    assert ctrl._problem.opts.max_nodes != 50, "per-call kwargs must not persist"
+
+
+def test_deep_cut_loop_claims_match_highs():
+    """round 1 withdrew deeper root cutting after ONE false optimality claim in this batch (23.1755 against 23.1641 at 12 rounds
+    x 80 Gomory cuts, gap 1e-4).  With the tiny-pivot guard every proven objective must be within the gap of HiGHS's optimum."""
+    from scipy.optimize import Bounds, LinearConstraint, milp
+    nb = 96
+    wl = syn.make_workload("cfg3", batch=nb)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    m = gpu.GpuModel([ag["mats"]], d)
+    cost = host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"])
+    raw = cn.standard_form(ag["mats"], ag["atoms"], wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
+    for kw in (dict(cut_rounds=12, cuts_per_round=80, max_cuts=400), dict()):
+        p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost, max_nodes=2000, gap_rel=1e-4, **kw)
+        out = p.solve(ag["x0"], ag["omega"])
+        p.close()
+        proven = np.where(out["status"] == 0)[0]
+        assert proven.size >= 0.9 * nb, (kw, proven.size)
+        for s in proven[:: 2 if kw else 4]:
+            h, q = cn.rhs(raw["evo"], ag["x0"][s], ag["omega"][s]), cn.lin_cost(raw["cost"], ag["x0"][s], ag["omega"][s])
+            r = cn.cost_const(raw["cost"]["const_terms"], ag["x0"][s], ag["omega"][s])
+            ref = milp(q, constraints=LinearConstraint(raw["G"], -np.inf, h), integrality=raw["is_bin"].astype(int),
+                       bounds=Bounds(raw["lb"], raw["ub"]), options=dict(mip_rel_gap=1e-7, time_limit=60))
+            if ref.status != 0:
+                continue
+            rel = (out["obj"][s] - (ref.fun + r)) / max(1.0, abs(ref.fun + r))
+            assert -1e-6 <= rel <= 2e-4, (kw, int(s), float(out["obj"][s]), float(ref.fun + r))
+            assert out["lower_bound"][s] <= ref.fun + r + 1e-6 * max(1.0, abs(ref.fun + r))
+    m.close()
+
+
+def test_rhs_and_cost_on_the_matrix_cores_fp64_and_fp32():
+    """K3 as one MFMA GEMM per model (batch = N dimension, instances of several models interleaved, ragged groups) against the
+    numpy restatement and against the vector-ALU kernel (opts.reserved bit 7); MLD_F32 within the fp32 tolerance (1e-5 of the
+    row's scale); K4's quadratic pull-back P = Gamma' (W + W') Gamma the same way."""
+    from pyhybridcontrol_amd import _lib
+    wl = syn.make_workload("cfg3", batch=150, n_agents=3, quadratic=True)
+    d = wl["agents"][0]["dims"]
+    N = wl["N_tilde"]
+    m = gpu.GpuModel([a["mats"] for a in wl["agents"]], d)
+    cost = host.stack_costs([host.cost_from_atoms(a["atoms"], d, wl["N_p"], N) for a in wl["agents"]])
+    x0 = np.concatenate([a["x0"] for a in wl["agents"]])
+    om = np.concatenate([a["omega"] for a in wl["agents"]])
+    rng = np.random.Generator(np.random.PCG64(11))
+    midx = np.repeat(np.arange(3), 150).astype(np.int32)
+    order = rng.permutation(450)[:401]                     # interleaved models, ragged last groups
+    x0, om, midx = x0[order], om[order], midx[order]
+    evos = [cn.condense(a["mats"], N) for a in wl["agents"]]
+    ref = np.stack([cn.rhs(evos[midx[b]], x0[b], om[b]) for b in range(401)])
+    scale = np.maximum(1.0, np.abs(ref).max(axis=0))
+    res = {}
+    for name, kw in (("mfma64", dict()), ("valu", dict(reserved=128)), ("mfma32", dict(flags=_lib.MLD_F32))):
+        p = gpu.GpuProblem(m, wl["N_p"], N, cost, **kw)
+        res[name] = (p.rhs(x0, om, midx), p.cost_assemble())
+        p.close()
+    assert np.abs(res["mfma64"][0] - ref).max() / scale.max() <= 1e-12
+    assert np.abs((res["mfma64"][0] - res["valu"][0]) / scale).max() <= 1e-12
+    err32 = np.abs((res["mfma32"][0] - ref) / scale).max()
+    assert 1e-12 < err32 <= 1e-5, err32                   # really fp32, and within the stated tolerance
+    P64, Pv, P32 = res["mfma64"][1]["P"], res["valu"][1]["P"], res["mfma32"][1]["P"]
+    ps = np.abs(Pv).max()
+    assert ps > 0 and np.abs(P64 - Pv).max() <= 1e-12 * ps
+    assert 1e-13 * ps < np.abs(P32 - Pv).max() <= 1e-5 * ps
+    for k in ("q0", "Qx", "Qw"):
+        s = max(1.0, np.abs(res["valu"][1][k]).max())
+        assert np.abs(res["mfma64"][1][k] - res["valu"][1][k]).max() <= 1e-12 * s, k
+        assert np.abs(res["mfma32"][1][k] - res["valu"][1][k]).max() <= 1e-5 * s, k
+    m.close()
