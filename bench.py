@@ -103,7 +103,9 @@ def cpu_baseline(agents, N_p, N_t, x0, om, midx, n_sample, gap, node_limit, pivo
     import tighten_np
     host = host_description()
     n_sample = min(n_sample, x0.shape[0])
-    idx = np.unique(np.linspace(0, x0.shape[0] - 1, n_sample).astype(np.int64))
+    step = max(1, x0.shape[0] // n_sample)
+    k = np.arange(n_sample)
+    idx = np.unique(np.minimum(k * step + k % step, x0.shape[0] - 1))      # spread over the scenarios, every agent
     forms, raw = {}, {}
     qs, Gs, hs = [], [], []
     for i in idx:

@@ -1,6 +1,6 @@
 """ORACLE (test infrastructure): golden OPTIMAL objectives of the benchmarked MILP instances, from a solver nobody here wrote.
 
-    python oracle/gen_solve_golden.py [--scen 16] [--procs 8]      # writes tests/golden/solve_cfg4_bench.npz, solve_cfg3.npz
+    python oracle/gen_solve_golden.py [--scen 32] [--cfg3 64] [--cfg5 32] [--procs 8]      # writes tests/golden/solve_cfg4_bench.npz, solve_cfg3.npz, solve_cfg5.npz
 
 The reference hands its solve to cvxpy -> Gurobi (controllers/controller_base.py:509); neither is installable here.  The
 independent checker is scipy.optimize.milp (HiGHS) at mip_rel_gap = 0 on the ORIGINAL (un-tightened, un-scaled) rows that
@@ -40,14 +40,15 @@ def highs_opt(sf, x0, om, gap=0.0, time_limit=120.0):
     return res.fun + r, getattr(res, "mip_dual_bound", np.nan) + r, int(getattr(res, "mip_node_count", -1)), int(res.status == 0), res.x
 
 
-def _init(kind, n_scen):
+def _init(kind, n_scen, gap=0.0, time_limit=120.0):
+    _G.update(gap=gap, time_limit=time_limit)
     if kind == "cfg4":
         import bench
         agents, N_p, N_t, x0, om, midx = bench.make_shard(64, n_scen, 0)
         _G.update(agents=agents, N_p=N_p, N_t=N_t, x0=x0, om=om, midx=midx, forms={})
     else:
         from pyhybridcontrol_amd import synthetic as syn
-        wl = syn.make_workload("cfg3", batch=n_scen)
+        wl = syn.make_workload(kind, batch=n_scen)
         ag = wl["agents"][0]
         _G.update(agents=[ag], N_p=wl["N_p"], N_t=wl["N_tilde"], x0=ag["x0"], om=ag["omega"],
                   midx=np.zeros(n_scen, np.int32), forms={})
@@ -63,12 +64,12 @@ def _form(a):
 def _one(i):
     a = int(_G["midx"][i])
     t0 = time.perf_counter()
-    obj, db, nodes, ok, _ = highs_opt(_form(a), _G["x0"][i], _G["om"][i])
+    obj, db, nodes, ok, _ = highs_opt(_form(a), _G["x0"][i], _G["om"][i], gap=_G.get("gap", 0.0), time_limit=_G.get("time_limit", 120.0))
     return i, obj, db, nodes, ok, time.perf_counter() - t0
 
 
-def run(kind, n_scen, n_inst, procs, out):
-    with mp.Pool(procs, initializer=_init, initargs=(kind, n_scen)) as pool:
+def run(kind, n_scen, n_inst, procs, out, gap=0.0, time_limit=120.0):
+    with mp.Pool(procs, initializer=_init, initargs=(kind, n_scen, gap, time_limit)) as pool:
         obj = np.full(n_inst, np.nan)
         db = np.full(n_inst, np.nan)
         nodes = np.zeros(n_inst, np.int64)
@@ -80,7 +81,7 @@ def run(kind, n_scen, n_inst, procs, out):
             if (k + 1) % 128 == 0:
                 print("%s: %d/%d  %.0fs" % (kind, k + 1, n_inst, time.perf_counter() - t0), flush=True)
     np.savez_compressed(out, obj=obj, dual_bound=db, nodes=nodes, proven=ok, highs_seconds=secs,
-                        n_scen=np.array(n_scen), solver=np.array("scipy.optimize.milp (HiGHS), mip_rel_gap=0, original rows"))
+                        n_scen=np.array(n_scen), gap=np.array(gap), solver=np.array("scipy.optimize.milp (HiGHS), mip_rel_gap=%g, original rows" % gap))
     print("wrote", out, "proven", int(ok.sum()), "of", n_inst, "| HiGHS seconds total %.0f max %.1f" % (secs.sum(), secs.max()))
 
 
@@ -88,6 +89,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--scen", type=int, default=16, help="scenarios of the cfg4 shard (x 64 agents)")
     ap.add_argument("--cfg3", type=int, default=64, help="cfg3 instances (agent 0 of make_workload('cfg3'))")
+    ap.add_argument("--cfg5", type=int, default=0, help="cfg5 instances (n = 2303, 784 binaries; HiGHS at mip_rel_gap 1e-4, minutes each)")
     ap.add_argument("--procs", type=int, default=8)
     args = ap.parse_args()
     gdir = os.path.join(ROOT, "tests", "golden")
@@ -95,3 +97,5 @@ if __name__ == "__main__":
         run("cfg4", args.scen, args.scen * 64, args.procs, os.path.join(gdir, "solve_cfg4_bench.npz"))
     if args.cfg3 > 0:
         run("cfg3", args.cfg3, args.cfg3, args.procs, os.path.join(gdir, "solve_cfg3.npz"))
+    if args.cfg5 > 0:
+        run("cfg5", args.cfg5, args.cfg5, args.procs, os.path.join(gdir, "solve_cfg5.npz"), gap=1e-4, time_limit=900.0)

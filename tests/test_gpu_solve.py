@@ -75,7 +75,7 @@ def test_cfg3_multi_model_batch_matches_oracle_or_reports_limit():
             if ref["status"] == "optimal":
                 assert abs(out["obj"][i] - (ref["obj"] + r)) <= 1e-6 * max(1.0, abs(ref["obj"] + r)), i
                 n_opt += 1
-    assert n_opt >= 6
+    assert n_opt >= 11, n_opt          # (round 1 asked for 6 of 12)
     p.close(); m.close()
 
 
@@ -291,7 +291,7 @@ def test_full_size_batch_properties_cfg3():
                        max_nodes=300)
     out = p.solve(ag["x0"], ag["omega"])
     fin = np.isfinite(out["obj"])
-    assert fin.mean() > 0.97 and (out["status"] == 0).mean() > 0.5
+    assert fin.all() and (out["status"] == 0).mean() >= 0.97, (fin.mean(), (out["status"] == 0).mean())     # (round 1: > 0.5)
     sf = cn.standard_form(ag["mats"], ag["atoms"], wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
     G, bins = sf["G"], sf["is_bin"]
     rown = np.maximum(1.0, np.abs(G).max(axis=1))
