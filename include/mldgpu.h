@@ -191,6 +191,13 @@ int mld_problem_set_opts(mld_problem_t *, const mld_opts *opts);
  * disturbance forecast moved on by one step (the first step re-enters at the end of the horizon).  The next
  * mld_solve_resident then solves the NEXT MPC step without any host traffic.  mld_download_inputs reads the current inputs. */
 int mld_advance_batch(mld_problem_t *);
+/* Scenario streaming with everything resident in HBM: the parameter update at the top of the reference's solve() (x_k and
+ * omega_tilde set as cvx.Parameter values, controllers/controller_base.py:495-498; the example re-solves with new forecasts every
+ * step, micro_grid_control_simulation.py:229-232) for a whole batch.  mld_stage_inputs uploads n_sets input sets of the uploaded
+ * batch's size (x0_sets: n_sets x batch x nx, omega_sets: n_sets x batch x N_tilde*nomega; model_idx and fixed_bin stay those of
+ * mld_upload_batch; n_sets = 0 frees them); mld_select_inputs makes set k the batch's current inputs by a device-to-device copy. */
+int mld_stage_inputs(mld_problem_t *, int n_sets, const double *x0_sets, const double *omega_sets);
+int mld_select_inputs(mld_problem_t *, int set);
 int mld_download_inputs(mld_problem_t *, double *x0, double *omega);
 
 /* Per-instance telemetry of the last solve: time spent inside the solve kernel (device wall clock, ns) and

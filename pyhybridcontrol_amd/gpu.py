@@ -231,6 +231,19 @@ class GpuProblem(object):
         disturbance forecast moved on by one step; the next solve_resident() is the next MPC step"""
         check(_lib.load().mld_advance_batch(self._h))
 
+    def stage(self, x0_sets, omega_sets):
+        """input sets of the uploaded batch's size resident in HBM (mld_stage_inputs): x0_sets (n_sets, batch, nx), omega_sets
+        (n_sets, batch, N_tilde*nomega); select(k) makes set k current without host traffic"""
+        d = self.model.dims
+        n_sets = int(np.shape(omega_sets)[0] if self.nW else np.shape(x0_sets)[0])
+        x0s = _lib.as_f64(x0_sets).reshape(n_sets, self.batch, d["nx"]) if d["nx"] else None
+        oms = _lib.as_f64(omega_sets).reshape(n_sets, self.batch, self.nW) if self.nW else None
+        check(_lib.load().mld_stage_inputs(self._h, n_sets, _lib.dptr(x0s), _lib.dptr(oms)))
+        return n_sets
+
+    def select(self, k):
+        check(_lib.load().mld_select_inputs(self._h, int(k)))
+
     def inputs(self):
         """current (x0, omega) of the resident batch"""
         d = self.model.dims

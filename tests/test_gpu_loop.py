@@ -150,3 +150,52 @@ def test_rhs_and_cost_on_the_matrix_cores_fp64_and_fp32():
         assert np.abs(res["mfma64"][1][k] - res["valu"][1][k]).max() <= 1e-12 * s, k
         assert np.abs(res["mfma32"][1][k] - res["valu"][1][k]).max() <= 1e-5 * s, k
     m.close()
+
+
+def test_gather_results_from_device_buffers_one_rank_communicator():
+    """mld_gather_results over a one-rank RCCL communicator (all a one-GPU box can host): (objective, status, step-0 slice) rows
+    equal the downloaded results"""
+    from pyhybridcontrol_amd import _lib
+    from pyhybridcontrol_amd.batch import RcclGather
+    wl = syn.make_workload("cfg2", batch=9)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    m = gpu.GpuModel([ag["mats"]], d)
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"]), gap_rel=1e-2, max_nodes=300)
+    out = p.solve(ag["x0"], ag["omega"])
+    g = RcclGather(1, 0, RcclGather.unique_id())
+    try:
+        rows = g.gather_results(p)
+    finally:
+        _lib.load().mld_comm_destroy()
+    assert rows.shape == (1, 9, 2 + m.nv)
+    assert np.array_equal(rows[0, :, 0], out["obj"]) and np.array_equal(rows[0, :, 1], out["status"].astype(float))
+    assert np.array_equal(rows[0, :, 2:], out["v"][:, :m.nv])
+    p.close(); m.close()
+
+
+def test_staged_input_sets_equal_direct_uploads():
+    """mld_stage_inputs / mld_select_inputs: a staged scenario set solved in place equals the same set uploaded from the host"""
+    wl = syn.make_workload("cfg2", batch=10, n_agents=2)
+    d = wl["agents"][0]["dims"]
+    N = wl["N_tilde"]
+    m = gpu.GpuModel([a["mats"] for a in wl["agents"]], d)
+    cost = host.stack_costs([host.cost_from_atoms(a["atoms"], d, wl["N_p"], N) for a in wl["agents"]])
+    p = gpu.GpuProblem(m, wl["N_p"], N, cost, gap_rel=1e-2, max_nodes=400)
+    midx = np.tile(np.arange(2), 10).astype(np.int32)
+    sets = []
+    for t in range(3):
+        rng = np.random.Generator(np.random.PCG64(100 + t))
+        sets.append(syn.make_scenarios(d["nx"], N, 20, rng))
+    p.upload(sets[0][0], sets[0][1], midx)
+    assert p.stage(np.stack([s[0] for s in sets]), np.stack([s[1] for s in sets])) == 3
+    for t in (2, 0, 1):
+        p.select(t)
+        x, w = p.inputs()
+        assert np.array_equal(x, sets[t][0]) and np.array_equal(w, sets[t][1])
+        p.solve_resident(); got = p.download()
+        ref = p.solve(sets[t][0], sets[t][1], midx)
+        assert np.array_equal(got["obj"], ref["obj"]) and np.array_equal(got["status"], ref["status"]) and np.array_equal(got["v"], ref["v"])
+    with pytest.raises(gpu.MldGpuError):
+        p.select(3)
+    p.close(); m.close()

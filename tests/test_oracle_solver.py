@@ -183,3 +183,30 @@ def test_unbounded_problem_is_reported_not_boxed():
     r = orc.solve_milp(np.array([1.0, 0.0]), np.array([[-1.0, 1.0]]), np.array([1.0]), np.array([-np.inf, 0.0]),
                        np.array([np.inf, 1.0]), np.array([0, 1], np.uint8))       # x >= y - 1 bounds it: optimum -1 at y = 0
     assert r["status"] == "optimal" and abs(r["obj"] + 1.0) < 1e-9
+
+
+def test_oracle_against_highs_golden_on_bench_instances():
+    """the C oracle (checker of the GPU tests, CPU baseline of bench.py) against optima nobody here computed: the first 32
+    instances of the bench shard vs tests/golden/solve_cfg4_bench.npz (scipy HiGHS, gap 0, original rows)"""
+    import os
+    import bench
+    import tighten_np
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "solve_cfg4_bench.npz"))
+    agents, N_p, N_t, x0, om, midx = bench.make_shard(64, 1, 0)
+    n = 32
+    qs, Gs, hs, rc = [], [], [], []
+    for i in range(n):
+        ag = agents[int(midx[i])]
+        d = ag["dims"]
+        sf = cn.standard_form(tighten_np.tighten(ag["mats"], d, nu_l=d["nu_l"]), ag["atoms"], N_p, N_t, nu_l=d["nu_l"])
+        qs.append(cn.lin_cost(sf["cost"], x0[i], om[i])); hs.append(cn.rhs(sf["evo"], x0[i], om[i])); Gs.append(sf["G"])
+        rc.append(cn.cost_const(sf["cost"]["const_terms"], x0[i], om[i]))
+    opt = gold["obj"][:n]
+    scale = np.maximum(1e-9, np.abs(opt))
+    for gap, nodes in ((1e-2, 800), (1e-6, 20000)):
+        r, _ = orc.solve_milp_batch(qs, Gs, hs, sf["lb"], sf["ub"], sf["is_bin"], threads=4, gap_rel=gap, max_nodes=nodes, presolve=0, max_pivots=400000)
+        obj, lb = r["obj"] + np.array(rc), r["lower_bound"] + np.array(rc)
+        assert np.all(obj >= opt - 1e-6 * scale) and np.all(lb <= opt + 1e-6 * scale)
+        proven = r["status"] == 0
+        assert proven.sum() >= n - 2
+        assert np.all(obj[proven] - opt[proven] <= gap * np.abs(obj[proven]) + 1e-6 * scale[proven])
