@@ -106,9 +106,10 @@ def cpu_baseline(agents, N_p, N_t, x0, om, midx, n_sample, gap, node_limit, pivo
     import tighten_np
     host = host_description()
     n_sample = min(n_sample, x0.shape[0])
-    step = max(1, x0.shape[0] // n_sample)
+    n_ag = len(agents)
+    n_sc = x0.shape[0] // n_ag
     k = np.arange(n_sample)
-    idx = np.unique(np.minimum(k * step + k % step, x0.shape[0] - 1))      # spread over the scenarios, every agent
+    idx = np.unique(((k * n_sc) // n_sample) * n_ag + (k * 37) % n_ag)      # instance i = scenario * n_agents + agent: scenarios spread over the shard, every agent
     forms, raw = {}, {}
     qs, Gs, hs = [], [], []
     for i in idx:

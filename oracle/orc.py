@@ -56,8 +56,8 @@ def _p(a):
     return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
 
 
-def make_opts(gap_abs=1e-9, gap_rel=0.0, max_nodes=100000, cut_rounds=8, cuts_per_round=40, max_cuts=200,
-              max_pivots=0, presolve=1, mir_per_round=20):
+def make_opts(gap_abs=1e-9, gap_rel=0.0, max_nodes=100000, cut_rounds=10, cuts_per_round=80, max_cuts=300,
+              max_pivots=0, presolve=1, mir_per_round=10):
     return Opts(gap_abs, gap_rel, max_nodes, cut_rounds, cuts_per_round, max_cuts, max_pivots, presolve, mir_per_round)
 
 

@@ -17,8 +17,13 @@ elif len(sys.argv) > 2 and sys.argv[2] == "wide":     # more Gomory cuts (cheap 
     configs = [dict(), dict(cuts_per_round=80, max_cuts=300), dict(cuts_per_round=80, max_cuts=300, mir_per_round=10),
                dict(cuts_per_round=80, max_cuts=300, mir_per_round=15), dict(cuts_per_round=120, max_cuts=400),
                dict(cuts_per_round=120, max_cuts=400, mir_per_round=10), dict(cuts_per_round=80, max_cuts=300, cut_rounds=10)]
+if len(sys.argv) > 2 and sys.argv[2] == "r2":      # round 2 (penalty branching, NodeLimit 800): the deep settings round 1 withdrew
+    configs = [dict(), dict(mir_per_round=10), dict(cuts_per_round=80, max_cuts=300, cut_rounds=10, mir_per_round=10),
+               dict(cuts_per_round=80, max_cuts=400, cut_rounds=12, mir_per_round=12), dict(cuts_per_round=80, max_cuts=400, cut_rounds=12, mir_per_round=20),
+               dict(cut_rounds=6), dict(cut_rounds=6, mir_per_round=10)]
+nodes = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 for kw in configs:
-    prob = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=1e-2, max_nodes=400, max_pivots=20000, **kw)
+    prob = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=1e-2, max_nodes=nodes, max_pivots=40000, **kw)
     prob.upload(x0, om, midx); prob.solve_resident(); st = prob.solve_resident()
     out = prob.download()
     ok = out['status'] == 0

@@ -101,11 +101,14 @@ def test_cfg3_against_highs_optimum():
 
 def test_cfg5_shape_against_highs_at_size():
     """BASELINE cfg5 shape (n = 2303, 784 binaries) at NodeLimit 400, MIPGap 1e-2, size-scaled cut budgets: every instance has an
-    incumbent, bounds bracket the HiGHS value (mip_rel_gap 1e-4), every OPTIMAL is within the gap; the proven share is asserted
-    at what the search reaches today (not yet adequate at this size)"""
+    incumbent, its objective is not below HiGHS's dual bound, the reported lower bound is not above HiGHS's incumbent, every
+    OPTIMAL is within the gap of HiGHS's bracket (HiGHS ran at mip_rel_gap 1e-4 with a 240 s limit per instance: its incumbent and
+    dual bound bracket the optimum also where the limit was hit).  The proven share is asserted at what the search reaches today
+    (not yet adequate at this size)."""
     gold = np.load(os.path.join(GDIR, "solve_cfg5.npz"))
     nb = int(gold["n_scen"])
-    ok = gold["proven"] == 1
+    ok = np.isfinite(gold["obj"]) & np.isfinite(gold["dual_bound"])
+    assert ok.sum() >= nb // 2
     wl = syn.make_workload("cfg5", batch=nb)
     ag = wl["agents"][0]
     d = ag["dims"]
@@ -117,12 +120,12 @@ def test_cfg5_shape_against_highs_at_size():
     st, obj, lb = out["status"], out["obj"], out["lower_bound"]
     assert np.all((st == 0) | (st == 2)), np.unique(st)
     assert np.all(np.isfinite(obj)), "every instance returns an incumbent"
-    hi, lo = gold["obj"][ok], gold["dual_bound"][ok]          # HiGHS: lo <= optimum <= hi, hi - lo <= 1e-4 |hi|
+    hi, lo = gold["obj"][ok], gold["dual_bound"][ok]          # HiGHS: lo <= optimum <= hi
     scale = np.maximum(1e-9, np.abs(hi))
     assert np.all(obj[ok] >= lo - 1e-6 * scale), "a feasible point below HiGHS's dual bound"
     assert np.all(lb[ok] <= hi + 1e-6 * scale), "lower bound above HiGHS's incumbent"
-    rel = (obj[ok] - lo) / scale
     claimed = st[ok] == 0
-    assert np.all(rel[claimed] <= 1e-2 * (1 + 1e-3) + 2e-4), rel[claimed].max()
-    print("cfg5: proven %d of %d, within 1 %% of HiGHS %d, worst %.3f" % ((st == 0).sum(), nb, (rel <= 1e-2 + 2e-4).sum(), rel.max()))
+    assert np.all(obj[ok][claimed] - hi[claimed] <= 1e-2 * np.abs(obj[ok][claimed]) + 1e-6 * scale[claimed]), "OPTIMAL outside the gap of HiGHS's incumbent"
+    rel = (obj[ok] - hi) / scale
+    print("cfg5: proven %d of %d, within 1 %% of HiGHS's incumbent %d of %d, worst %.3f" % ((st == 0).sum(), nb, (rel <= 1e-2).sum(), ok.sum(), rel.max()))
     assert (st == 0).mean() >= 0.25
