@@ -21,7 +21,7 @@ from . import gpu
 from ._lib import MldGpuError, STATUS_NAMES
 from .mld_model import MldModel
 from .mld_model import ParNotSet
-from .objective_atoms import ObjectiveAtoms, atleast_2d_col
+from .objective_atoms import ObjectiveAtoms, atleast_2d_col, matmul
 
 
 class ControllerBuildRequiredError(RuntimeError):
@@ -577,8 +577,8 @@ class MpcController(object):
         o1, o2, o3 = info.nu, info.nu + info.ndelta, info.nu + info.ndelta + info.nz
         out.update(v=v, u=v[:o1], delta=v[o1:o2], z=v[o2:o3], mu=v[o3:])
         m = self._model
-        out["y"] = (m["C"] @ out["x"] + m["D1"] @ out["u"] + m["D2"] @ out["delta"] + m["D3"] @ out["z"]
-                    + m["D4"] @ out["omega"] + m["d5"])
+        out["y"] = (matmul(m["C"], out["x"]) + matmul(m["D1"], out["u"]) + matmul(m["D2"], out["delta"]) + matmul(m["D3"], out["z"])
+                    + matmul(m["D4"], out["omega"]) + m["d5"])
         return out
 
     @property
@@ -589,10 +589,10 @@ class MpcController(object):
         """x_N_tilde and y_N_tilde of the last solution (variables.py:259-275) from the K1/K2 matrices"""
         evo = self.mld_evo_matrices
         s, o = evo.state_input, evo.output
-        x = s["Phi_x_N_tilde"] @ self._x_k + s["Gamma_v_N_tilde"] @ self._solution + \
-            s["Gamma_omega_N_tilde"] @ self._omega_tilde_k + s["Gamma_5_N_tilde"]
-        y = o["L_x_N_tilde"] @ self._x_k + o["L_v_N_tilde"] @ self._solution + \
-            o["L_omega_N_tilde"] @ self._omega_tilde_k + o["L_5_N_tilde"]
+        x = matmul(s["Phi_x_N_tilde"], self._x_k) + matmul(s["Gamma_v_N_tilde"], self._solution) + \
+            matmul(s["Gamma_omega_N_tilde"], self._omega_tilde_k) + s["Gamma_5_N_tilde"]
+        y = matmul(o["L_x_N_tilde"], self._x_k) + matmul(o["L_v_N_tilde"], self._solution) + \
+            matmul(o["L_omega_N_tilde"], self._omega_tilde_k) + o["L_5_N_tilde"]
         return x, y
 
     def sim_step_k(self, k, x_k=None, u_k=None, omega_k=None, mld_numeric_k=None, solver=None, step_state=True):

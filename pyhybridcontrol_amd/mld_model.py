@@ -11,7 +11,8 @@ out of scope: matrices are plain read-only ndarray
 """
 import numpy as np
 
-from .objective_atoms import atleast_2d_col
+
+from .objective_atoms import atleast_2d_col, matmul
 
 
 class _ParNotSetType(object):
@@ -274,11 +275,11 @@ class MldModel(object):
             u_k, delta_k, z_k, mu_k = v_k[:o1], v_k[o1:o2], v_k[o2:o3], v_k[o3:]
         u_k, delta_k, z_k, mu_k = col(u_k, info.nu), col(delta_k, info.ndelta), col(z_k, info.nz), col(mu_k, info.nmu)
         m = self._mats
-        x_k1 = m["A"] @ x_k + m["B1"] @ u_k + m["B2"] @ delta_k + m["B3"] @ z_k + m["B4"] @ omega_k + m["b5"]
-        y_k = m["C"] @ x_k + m["D1"] @ u_k + m["D2"] @ delta_k + m["D3"] @ z_k + m["D4"] @ omega_k + m["d5"]
+        x_k1 = matmul(m["A"], x_k) + matmul(m["B1"], u_k) + matmul(m["B2"], delta_k) + matmul(m["B3"], z_k) + matmul(m["B4"], omega_k) + m["b5"]
+        y_k = matmul(m["C"], x_k) + matmul(m["D1"], u_k) + matmul(m["D2"], delta_k) + matmul(m["D3"], z_k) + matmul(m["D4"], omega_k) + m["d5"]
         f5 = m["f5"] if m["f5"].size else np.zeros((info.n_constraints, 1))
-        cons = (m["E"] @ x_k + m["F1"] @ u_k + m["F2"] @ delta_k + m["F3"] @ z_k + m["F4"] @ omega_k + m["G"] @ y_k
-                + m["Psi"] @ (mu_k * 0) - f5 <= cons_tol)          # hard-constraint satisfaction, as :692-694
+        cons = (matmul(m["E"], x_k) + matmul(m["F1"], u_k) + matmul(m["F2"], delta_k) + matmul(m["F3"], z_k) + matmul(m["F4"], omega_k) + matmul(m["G"], y_k)
+                + matmul(m["Psi"], (mu_k * 0)) - f5 <= cons_tol)          # hard-constraint satisfaction, as :692-694
         return dict(x_k1=x_k1, x=x_k, u=u_k, delta=delta_k, z=z_k, mu=mu_k, v=np.vstack((u_k, delta_k, z_k, mu_k)),
                     y=y_k, omega=omega_k, cons=cons)
 

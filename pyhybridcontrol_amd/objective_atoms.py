@@ -28,6 +28,19 @@ def atleast_2d_col(a):
     return a
 
 
+def is_scalar_like(val):
+    """utils/matrix_utils.py:20-22: every dimension is 1 (objects without a shape count as scalars)"""
+    return all(dd == 1 for dd in getattr(val, "shape", (1,)))
+
+
+def matmul(a, b):
+    """utils/matrix_utils.py:24-28: elementwise product when either operand is scalar-like (1 x 1 matrices broadcast), the
+    matrix product otherwise -- the rule every `H_x x_k`, `Phi_x x_k`, `C x` of the reference goes through"""
+    if is_scalar_like(a) or is_scalar_like(b):
+        return a * b
+    return a @ b
+
+
 def parse_key(key):
     info = key.split("_")
     weight_type = "vector" if "".join(info[0:1]).islower() else "matrix"

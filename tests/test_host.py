@@ -390,3 +390,16 @@ def test_schedule_params_make_the_step_models_of_a_horizon():
     assert same[0] is same[1] is same[2] and same[0]["A"][0, 0] == 0.9
     with pytest.raises(ValueError, match="must be equal to N_tilde"):
         phc.get_mld_numeric_tilde(make, 4, ps, sched)
+
+
+def test_matmul_scalar_broadcast_rule():
+    """utils/matrix_utils.py:20-28: `matmul` multiplies elementwise when either operand is scalar-like (all dims 1), else `@`"""
+    from pyhybridcontrol_amd.objective_atoms import matmul, is_scalar_like, atleast_2d_col
+    A = np.arange(6.0).reshape(3, 2)
+    assert is_scalar_like(np.ones((1, 1))) and is_scalar_like(2.5) and is_scalar_like(np.ones((1, 1, 1))) and not is_scalar_like(np.ones((1, 2)))
+    assert np.array_equal(matmul(A, np.array([[2.0]])), 2.0 * A)            # (3,2) "times" a 1x1 matrix broadcasts; A @ [[2.]] would raise
+    assert np.array_equal(matmul(np.array([[2.0]]), A), 2.0 * A)
+    assert np.array_equal(matmul(A, atleast_2d_col([1.0, -1.0])), A @ np.array([[1.0], [-1.0]]))
+    assert np.array_equal(matmul(3.0, A), 3.0 * A)
+    with pytest.raises(ValueError):
+        matmul(A, np.ones((3, 1)))                                           # a real shape mismatch still fails
