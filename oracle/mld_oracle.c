@@ -1509,3 +1509,314 @@ int orc_solve_milp_batch(int n_inst, int n, int m, const double *const *q, const
     }
     return used;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * (4) LP relaxation by a REVISED bounded dual simplex on the working basis (the formulation of the LDS-resident kernel
+ *     k_lp_lds, csrc/lp_lds.inc): instead of a dense (m x n) dictionary only the inverse of the working basis
+ *         W = G[T, B]   (T: tight rows = non-basic slacks, B: basic structurals, |T| = |B| = k, measured k <= 75 at cfg3)
+ *     is kept (k x k), and every dictionary row / column the simplex needs is formed on the fly from W^-1 and rows / columns of G:
+ *         row of basic structural B_p :  D[p, j] = rho . G[T, j],  D[p, s_t] = rho_t            with rho = W^-1[p, :]
+ *         row of basic slack i        :  D[i, j] = G[i, j] - u . G[T, j],  D[i, s_t] = -u_t     with u = G[i, B] W^-1
+ *         reduced costs               :  d_j = q_j - pi . G[T, j],  d_{s_t} = -pi_t             with pi = W^-T q_B
+ *     The four basis changes (structural / slack entering x structural / slack leaving) replace a column of W, replace a row,
+ *     border it or delete a row and a column: O(k^2) updates of W^-1.  Same tolerances, Harris ratio test and Bland fallback as
+ *     dual_simplex() above; W^-1 and all primal / dual values are recomputed from G every ORC_REV_REFRESH pivots.
+ * ---------------------------------------------------------------------------------------------- */
+#define ORC_REV_REFRESH 50
+
+typedef struct {
+    int n, m, k, kcap;
+    const double *G;            /* scaled m x n */
+    const double *h, *q;        /* scaled */
+    double *lo, *hi;            /* structural bounds (scaled); free variables are boxed at +-ORC_BIG when they rest non-basic */
+    double *x, *s;              /* structural values (n), slack values (m; 0 when tight) */
+    int *posB, *posT;           /* structural -> position in B or -1; row -> position in T or -1 */
+    unsigned char *up;          /* non-basic structural rests at its upper bound */
+    int *Bs, *T;
+    double *Winv;               /* kcap x kcap: rows = positions of B, columns = positions of T */
+    double *d, *dS;             /* reduced costs: non-basic structurals (n), non-basic slacks by position (kcap) */
+    double *alpha, *alphaS, *rho, *w, *col;
+    unsigned char *skipX, *skipS;   /* violations within the skip tolerance without an eligible pivot: left alone for this solve */
+    long pivots, refreshes;
+} rev_t;
+
+static int rev_refresh(rev_t *r)
+{   /* W^-1 by Gauss-Jordan with partial pivoting, then x_B, s, pi, d from the original data */
+    const int n = r->n, m = r->m, k = r->k, kc = r->kcap;
+    double *Wm = dalloc((size_t)k * 2 * k);
+    for (int t = 0; t < k; ++t) {
+        for (int p = 0; p < k; ++p) Wm[(size_t)t * 2 * k + p] = r->G[(size_t)r->T[t] * n + r->Bs[p]];
+        for (int p = 0; p < k; ++p) Wm[(size_t)t * 2 * k + k + p] = (p == t) ? 1.0 : 0.0;
+    }
+    for (int c = 0; c < k; ++c) {
+        int pv = c; double mx = fabs(Wm[(size_t)c * 2 * k + c]);
+        for (int a = c + 1; a < k; ++a) if (fabs(Wm[(size_t)a * 2 * k + c]) > mx) { mx = fabs(Wm[(size_t)a * 2 * k + c]); pv = a; }
+        if (mx < 1e-13) { free(Wm); return 0; }
+        if (pv != c) for (int b = 0; b < 2 * k; ++b) { const double t2 = Wm[(size_t)c * 2 * k + b]; Wm[(size_t)c * 2 * k + b] = Wm[(size_t)pv * 2 * k + b]; Wm[(size_t)pv * 2 * k + b] = t2; }
+        const double inv = 1.0 / Wm[(size_t)c * 2 * k + c];
+        for (int b = 0; b < 2 * k; ++b) Wm[(size_t)c * 2 * k + b] *= inv;
+        for (int a = 0; a < k; ++a) {
+            if (a == c) continue;
+            const double f = Wm[(size_t)a * 2 * k + c];
+            if (f != 0.0) for (int b = 0; b < 2 * k; ++b) Wm[(size_t)a * 2 * k + b] -= f * Wm[(size_t)c * 2 * k + b];
+        }
+    }
+    /* [W | I] -> [I | W^-1]: W^-1[p][t] sits at row p, column k + t */
+    for (int p = 0; p < k; ++p) for (int t = 0; t < k; ++t) r->Winv[(size_t)p * kc + t] = Wm[(size_t)p * 2 * k + k + t];
+    free(Wm);
+    /* x_B = W^-1 (h_T - G[T, N] x_N) */
+    double *rhs = dalloc(k);
+    for (int t = 0; t < k; ++t) {
+        const double *g = r->G + (size_t)r->T[t] * n;
+        double a = r->h[r->T[t]];
+        for (int j = 0; j < n; ++j) if (r->posB[j] < 0) a -= g[j] * r->x[j];
+        rhs[t] = a;
+    }
+    for (int p = 0; p < k; ++p) { double a = 0; for (int t = 0; t < k; ++t) a += r->Winv[(size_t)p * kc + t] * rhs[t]; r->x[r->Bs[p]] = a; }
+    for (int i = 0; i < m; ++i) {
+        if (r->posT[i] >= 0) { r->s[i] = 0.0; continue; }
+        const double *g = r->G + (size_t)i * n;
+        double a = r->h[i];
+        for (int j = 0; j < n; ++j) a -= g[j] * r->x[j];
+        r->s[i] = a;
+    }
+    /* pi = W^-T q_B ; d_j = q_j - pi . G[T, j] ; dS_t = -pi_t */
+    for (int t = 0; t < k; ++t) { double a = 0; for (int p = 0; p < k; ++p) a += r->Winv[(size_t)p * kc + t] * r->q[r->Bs[p]]; rhs[t] = a; }
+    for (int j = 0; j < n; ++j) {
+        if (r->posB[j] >= 0) { r->d[j] = 0.0; continue; }
+        double a = r->q[j];
+        for (int t = 0; t < k; ++t) a -= rhs[t] * r->G[(size_t)r->T[t] * n + j];
+        r->d[j] = a;
+    }
+    for (int t = 0; t < k; ++t) r->dS[t] = -rhs[t];
+    free(rhs);
+    r->refreshes++;
+    return 1;
+}
+
+/* returns LP_OPTIMAL / LP_INFEASIBLE / LP_ITERLIMIT */
+static int rev_dual_simplex(rev_t *r, long max_pivots)
+{
+    const int n = r->n, m = r->m, kc = r->kcap;
+    int stall = 0; double last_obj = -INFINITY; long since = 0;
+    memset(r->skipX, 0, (size_t)n); memset(r->skipS, 0, (size_t)m);
+    for (;;) {
+        if (r->pivots >= max_pivots) return LP_ITERLIMIT;
+        if (since >= ORC_REV_REFRESH) { since = 0; if (!rev_refresh(r)) return LP_ITERLIMIT; }
+        const int k = r->k;
+        double cur = 0; for (int j = 0; j < n; ++j) cur += r->q[j] * r->x[j];
+        if (cur > last_obj + 1e-12 * fmax(1.0, fabs(cur))) { stall = 0; last_obj = cur; } else stall++;
+        const int bland = stall > 30;
+        /* ---- leaving variable: largest bound violation (smallest id while stalling); ids: structural j, slack n + i */
+        int lv = -1, lv_bl = -1, id_bl = 0x7fffffff; double best = ORC_PTOL;
+        for (int p = 0; p < k; ++p) {
+            const int j = r->Bs[p];
+            if (r->skipX[j]) continue;
+            const double v = fmax(r->lo[j] - r->x[j], r->x[j] - r->hi[j]);
+            if (v > ORC_PTOL) { if (v > best) { best = v; lv = j; } if (j < id_bl) { id_bl = j; lv_bl = j; } }
+        }
+        for (int i = 0; i < m; ++i) {
+            if (r->posT[i] >= 0 || r->skipS[i]) continue;
+            const double v = -r->s[i];
+            if (v > ORC_PTOL) { if (v > best) { best = v; lv = n + i; } if (n + i < id_bl) { id_bl = n + i; lv_bl = n + i; } }
+        }
+        if (lv < 0) {
+            if (since > 0) { since = 0; if (!rev_refresh(r)) return LP_ITERLIMIT; continue; }   /* verify at a clean state before declaring optimality */
+            return LP_OPTIMAL;
+        }
+        if (bland) lv = lv_bl;
+        /* ---- its dictionary row over the non-basic structurals (alpha) and the non-basic slacks (alphaS) */
+        int below; double viol, xl;
+        if (lv < n) {
+            const int p = r->posB[lv];
+            for (int t = 0; t < k; ++t) r->rho[t] = r->Winv[(size_t)p * kc + t];
+            for (int j = 0; j < n; ++j) {
+                if (r->posB[j] >= 0) { r->alpha[j] = 0.0; continue; }
+                double a = 0; for (int t = 0; t < k; ++t) a += r->rho[t] * r->G[(size_t)r->T[t] * n + j];
+                r->alpha[j] = a;
+            }
+            for (int t = 0; t < k; ++t) r->alphaS[t] = r->rho[t];
+            xl = r->x[lv];
+            const double vlo = r->lo[lv] - xl, vhi = xl - r->hi[lv];
+            below = vlo > vhi; viol = below ? vlo : vhi;
+        } else {
+            const int i = lv - n;
+            const double *gi = r->G + (size_t)i * n;
+            for (int t = 0; t < k; ++t) { double a = 0; for (int p = 0; p < k; ++p) a += gi[r->Bs[p]] * r->Winv[(size_t)p * kc + t]; r->rho[t] = a; }
+            for (int j = 0; j < n; ++j) {
+                if (r->posB[j] >= 0) { r->alpha[j] = 0.0; continue; }
+                double a = gi[j]; for (int t = 0; t < k; ++t) a -= r->rho[t] * r->G[(size_t)r->T[t] * n + j];
+                r->alpha[j] = a;
+            }
+            for (int t = 0; t < k; ++t) r->alphaS[t] = -r->rho[t];
+            xl = r->s[i]; below = 1; viol = -xl;
+        }
+        /* ---- ratio test (Harris two-pass; eligibility as in dual_simplex) */
+        double emax = 0;
+        for (int j = 0; j < n; ++j) {
+            if (r->posB[j] >= 0 || r->lo[j] == r->hi[j]) continue;
+            const double a = r->alpha[j];
+            const int el = below ? (r->up[j] ? a > 0 : a < 0) : (r->up[j] ? a < 0 : a > 0);
+            if (el && fabs(a) > emax) emax = fabs(a);
+        }
+        for (int t = 0; t < k; ++t) { const double a = r->alphaS[t]; const int el = below ? a < 0 : a > 0; if (el && fabs(a) > emax) emax = fabs(a); }
+        const double ptol = fmax(ORC_PIV_ABS, ORC_PIV_REL * emax);
+        double tmax = INFINITY, rmin = INFINITY; int any = 0;
+        for (int j = 0; j < n; ++j) {
+            if (r->posB[j] >= 0 || r->lo[j] == r->hi[j]) continue;
+            const double a = r->alpha[j];
+            const int el = below ? (r->up[j] ? a > 0 : a < 0) : (r->up[j] ? a < 0 : a > 0);
+            if (!el || fabs(a) <= ptol) continue;
+            any = 1;
+            const double da = fmax(r->up[j] ? -r->d[j] : r->d[j], 0.0);
+            tmax = fmin(tmax, (da + ORC_DTOL) / fabs(a)); rmin = fmin(rmin, da / fabs(a));
+        }
+        for (int t = 0; t < k; ++t) {
+            const double a = r->alphaS[t];
+            const int el = below ? a < 0 : a > 0;
+            if (!el || fabs(a) <= ptol) continue;
+            any = 1;
+            const double da = fmax(r->dS[t], 0.0);
+            tmax = fmin(tmax, (da + ORC_DTOL) / fabs(a)); rmin = fmin(rmin, da / fabs(a));
+        }
+        if (!any) {
+            if (viol <= ORC_PTOL_SKIP) { if (lv < n) r->skipX[lv] = 1; else r->skipS[lv - n] = 1; continue; }
+            if (since > 0) { since = 0; if (!rev_refresh(r)) return LP_ITERLIMIT; continue; }
+            return LP_INFEASIBLE;
+        }
+        int q = -1; double abest = -1; int idbest = 0x7fffffff;      /* q: structural j, or n + position t for a slack */
+        for (int j = 0; j < n; ++j) {
+            if (r->posB[j] >= 0 || r->lo[j] == r->hi[j]) continue;
+            const double a = r->alpha[j];
+            const int el = below ? (r->up[j] ? a > 0 : a < 0) : (r->up[j] ? a < 0 : a > 0);
+            if (!el || fabs(a) <= ptol) continue;
+            const double r0 = fmax(r->up[j] ? -r->d[j] : r->d[j], 0.0) / fabs(a);
+            if (bland) { if (r0 <= rmin * (1 + 1e-12) + 1e-300 && j < idbest) { idbest = j; q = j; } }
+            else if (r0 <= tmax && fabs(a) > abest) { abest = fabs(a); q = j; }
+        }
+        for (int t = 0; t < k; ++t) {
+            const double a = r->alphaS[t];
+            const int el = below ? a < 0 : a > 0;
+            if (!el || fabs(a) <= ptol) continue;
+            const double r0 = fmax(r->dS[t], 0.0) / fabs(a);
+            const int id = n + r->T[t];
+            if (bland) { if (r0 <= rmin * (1 + 1e-12) + 1e-300 && id < idbest) { idbest = id; q = n + t; } }
+            else if (r0 <= tmax && fabs(a) > abest) { abest = fabs(a); q = n + t; }
+        }
+        const double aq = q < n ? r->alpha[q] : r->alphaS[q - n];
+        if (fabs(aq) < ORC_PIV_TINY && viol <= ORC_PTOL_SKIP) { if (lv < n) r->skipX[lv] = 1; else r->skipS[lv - n] = 1; continue; }
+        /* ---- column of the entering variable: w over the basic structurals, col over the basic slacks */
+        if (q < n) {
+            for (int p = 0; p < k; ++p) { double a = 0; for (int t = 0; t < k; ++t) a += r->Winv[(size_t)p * kc + t] * r->G[(size_t)r->T[t] * n + q]; r->w[p] = a; }
+        } else for (int p = 0; p < k; ++p) r->w[p] = r->Winv[(size_t)p * kc + (q - n)];
+        const double leave_value = lv < n ? (below ? r->lo[lv] : r->hi[lv]) : 0.0;
+        const double theta = (xl - leave_value) / aq;
+        for (int p = 0; p < k; ++p) r->x[r->Bs[p]] -= r->w[p] * theta;
+        for (int i = 0; i < m; ++i) {
+            if (r->posT[i] >= 0) continue;
+            const double *gi = r->G + (size_t)i * n;
+            double c = q < n ? gi[q] : 0.0;
+            for (int p = 0; p < k; ++p) c -= gi[r->Bs[p]] * r->w[p];
+            r->col[i] = c;
+            r->s[i] -= c * theta;
+        }
+        /* ---- reduced costs */
+        const double dq = q < n ? r->d[q] : r->dS[q - n];
+        const double tau = dq / aq;
+        for (int j = 0; j < n; ++j) if (r->posB[j] < 0) r->d[j] -= tau * r->alpha[j];
+        for (int t = 0; t < k; ++t) r->dS[t] -= tau * r->alphaS[t];
+        /* ---- basis change */
+        if (q < n && lv < n) {                   /* structural enters, structural leaves: column p of W replaced */
+            const int p = r->posB[lv];
+            const double inv = 1.0 / r->w[p];
+            for (int t = 0; t < k; ++t) r->Winv[(size_t)p * kc + t] *= inv;
+            for (int a = 0; a < k; ++a) { if (a == p) continue; const double f = r->w[a]; if (f != 0.0) for (int t = 0; t < k; ++t) r->Winv[(size_t)a * kc + t] -= f * r->Winv[(size_t)p * kc + t]; }
+            r->x[q] += theta; r->x[lv] = leave_value;
+            r->Bs[p] = q; r->posB[q] = p; r->posB[lv] = -1;
+            r->up[lv] = (leave_value == r->hi[lv]) && (r->lo[lv] != r->hi[lv]);
+            r->d[lv] = -tau; r->d[q] = 0.0;
+        } else if (q >= n && lv >= n) {          /* slack enters (row leaves T), slack leaves (row becomes tight): row t of W replaced */
+            const int t = q - n, i = lv - n, told = r->T[t];
+            const double inv = 1.0 / r->rho[t];      /* rho = G[i, B] W^-1 */
+            for (int p = 0; p < k; ++p) r->Winv[(size_t)p * kc + t] *= inv;
+            for (int b = 0; b < k; ++b) { if (b == t) continue; const double f = r->rho[b]; if (f != 0.0) for (int p = 0; p < k; ++p) r->Winv[(size_t)p * kc + b] -= f * r->Winv[(size_t)p * kc + t]; }
+            r->s[told] = theta; r->s[i] = 0.0;
+            r->T[t] = i; r->posT[i] = t; r->posT[told] = -1;
+            r->dS[t] = -tau;
+        } else if (q < n && lv >= n) {           /* structural enters, slack leaves: W bordered by row i and column q (k + 1) */
+            const int i = lv - n;
+            if (k + 1 > kc) return LP_ITERLIMIT;
+            const double sig = aq;                  /* Schur complement G[i, q] - G[i, B] W^-1 G[T, q] = the pivot element */
+            const double inv = 1.0 / sig;
+            for (int p = 0; p < k; ++p) for (int t = 0; t < k; ++t) r->Winv[(size_t)p * kc + t] += r->w[p] * r->rho[t] * inv;
+            for (int p = 0; p < k; ++p) r->Winv[(size_t)p * kc + k] = -r->w[p] * inv;
+            for (int t = 0; t < k; ++t) r->Winv[(size_t)k * kc + t] = -r->rho[t] * inv;
+            r->Winv[(size_t)k * kc + k] = inv;
+            r->x[q] += theta; r->s[i] = 0.0;
+            r->Bs[k] = q; r->posB[q] = k; r->T[k] = i; r->posT[i] = k;
+            r->dS[k] = -tau; r->d[q] = 0.0;
+            r->k = k + 1;
+        } else {                                 /* slack enters (row leaves T), structural leaves: row t and column p of W removed */
+            const int t = q - n, p = r->posB[lv], told = r->T[t];
+            const double inv = 1.0 / r->Winv[(size_t)p * kc + t];
+            for (int a = 0; a < k; ++a) {
+                if (a == p) continue;
+                const double f = r->Winv[(size_t)a * kc + t] * inv;
+                if (f != 0.0) for (int b = 0; b < k; ++b) if (b != t) r->Winv[(size_t)a * kc + b] -= f * r->Winv[(size_t)p * kc + b];
+            }
+            r->s[told] = theta; r->x[lv] = leave_value;
+            r->posB[lv] = -1; r->posT[told] = -1;
+            r->up[lv] = (leave_value == r->hi[lv]) && (r->lo[lv] != r->hi[lv]);
+            r->d[lv] = -tau;
+            /* compact: move the last position into the holes (row p of W^-1 <- last row, column t <- last column) */
+            const int last = k - 1;
+            if (p != last) { for (int b = 0; b < k; ++b) r->Winv[(size_t)p * kc + b] = r->Winv[(size_t)last * kc + b]; r->Bs[p] = r->Bs[last]; r->posB[r->Bs[p]] = p; }
+            if (t != last) { for (int a = 0; a < k; ++a) r->Winv[(size_t)a * kc + t] = r->Winv[(size_t)a * kc + last]; r->T[t] = r->T[last]; r->posT[r->T[t]] = t; r->dS[t] = r->dS[last]; }
+            r->k = k - 1;
+        }
+        r->pivots++; since++;
+    }
+}
+
+/* min q'x  s.t. Gx <= h, lb <= x <= ub (no integers): the LP by the revised method; same scaling as orc_solve_miqp */
+int orc_lp_revised(int n, int m, const double *q, const double *G, const double *h, const double *lb, const double *ub, int kcap, long max_pivots,
+                   double *x_out, double *obj_out, orc_stats *st)
+{
+    memset(st, 0, sizeof(*st));
+    *obj_out = INFINITY;
+    unsigned char *noint = (unsigned char *)calloc(n + 1, 1);
+    double *rs = dalloc(m), *cs = dalloc(n);
+    equilibrate(G, m, n, noint, rs, cs);
+    double *Gs = dalloc((size_t)m * n), *hs = dalloc(m), *qs = dalloc(n);
+    for (int i = 0; i < m; ++i) { for (int j = 0; j < n; ++j) Gs[(size_t)i * n + j] = G[(size_t)i * n + j] * rs[i] * cs[j]; hs[i] = h[i] * rs[i]; }
+    rev_t R; rev_t *r = &R; memset(r, 0, sizeof(R));
+    r->n = n; r->m = m; r->k = 0; r->kcap = kcap; r->G = Gs; r->h = hs; r->q = qs;
+    r->lo = dalloc(n); r->hi = dalloc(n); r->x = dalloc(n); r->s = dalloc(m);
+    r->posB = (int *)calloc(n + 1, sizeof(int)); r->posT = (int *)calloc(m + 1, sizeof(int));
+    r->up = (unsigned char *)calloc(n + 1, 1);
+    r->Bs = (int *)calloc(kcap + 1, sizeof(int)); r->T = (int *)calloc(kcap + 1, sizeof(int));
+    r->Winv = dalloc((size_t)kcap * kcap); r->d = dalloc(n); r->dS = dalloc(kcap);
+    r->alpha = dalloc(n); r->alphaS = dalloc(kcap); r->rho = dalloc(kcap); r->w = dalloc(kcap); r->col = dalloc(m);
+    r->skipX = (unsigned char *)calloc(n + 1, 1); r->skipS = (unsigned char *)calloc(m + 1, 1);
+    for (int j = 0; j < n; ++j) {
+        qs[j] = q[j] * cs[j]; r->lo[j] = lb[j] / cs[j]; r->hi[j] = ub[j] / cs[j];
+        r->posB[j] = -1; r->d[j] = qs[j];
+        /* slack basis: every structural non-basic at its dual-feasible bound (place() of the dense code) */
+        if (r->lo[j] == r->hi[j]) { r->up[j] = 0; r->x[j] = r->lo[j]; }
+        else if (qs[j] >= 0) { if (!isfinite(r->lo[j])) r->lo[j] = -ORC_BIG; r->up[j] = 0; r->x[j] = r->lo[j]; }
+        else { if (!isfinite(r->hi[j])) r->hi[j] = ORC_BIG; r->up[j] = 1; r->x[j] = r->hi[j]; }
+    }
+    for (int i = 0; i < m; ++i) r->posT[i] = -1;
+    rev_refresh(r);
+    const int lp = rev_dual_simplex(r, max_pivots > 0 ? max_pivots : 2000000000L);
+    int status = lp == LP_OPTIMAL ? ORC_OPTIMAL : (lp == LP_INFEASIBLE ? ORC_INFEASIBLE : ORC_NUMERICAL);
+    if (lp == LP_OPTIMAL) {
+        double ob = 0;
+        for (int j = 0; j < n; ++j) { x_out[j] = r->x[j] * cs[j]; ob += q[j] * x_out[j]; }
+        *obj_out = ob;
+    }
+    st->pivots = (int)r->pivots; st->refactors = (int)r->refreshes; st->status = status; st->nodes = r->k;
+    free(noint); free(rs); free(cs); free(Gs); free(hs); free(qs); free(r->lo); free(r->hi); free(r->x); free(r->s); free(r->posB); free(r->posT);
+    free(r->up); free(r->Bs); free(r->T); free(r->Winv); free(r->d); free(r->dS); free(r->alpha); free(r->alphaS); free(r->rho); free(r->w); free(r->col); free(r->skipX); free(r->skipS);
+    return status;
+}

@@ -108,6 +108,23 @@ def solve_milp_batch(qs, Gs, hs, lb, ub, is_bin, threads=0, **kw):
     return dict(obj=obj, status=st, nodes=nd, pivots=pv, lower_bound=lbd), used
 
 
+def lp_revised(q, G, h, lb, ub, kcap=128, max_pivots=0):
+    """the LP min q'x, Gx <= h, lb <= x <= ub by the revised dual simplex on the working basis (orc_lp_revised): the CPU
+    restatement of the LDS-resident kernel's formulation.  Returns status, obj, x, pivots, refreshes, k (final basis size)."""
+    q = np.ascontiguousarray(q, np.float64)
+    G = np.ascontiguousarray(G, np.float64)
+    h = np.ascontiguousarray(h, np.float64)
+    lb = np.ascontiguousarray(lb, np.float64)
+    ub = np.ascontiguousarray(ub, np.float64)
+    m, n = G.shape
+    x = np.zeros(n)
+    obj = C.c_double()
+    st = Stats()
+    lib().orc_lp_revised.restype = C.c_int
+    s = lib().orc_lp_revised(n, m, _p(q), _p(G), _p(h), _p(lb), _p(ub), int(kcap), C.c_long(int(max_pivots)), _p(x), C.byref(obj), C.byref(st))
+    return dict(status=STATUS[s], obj=obj.value, x=x, pivots=st.pivots, refreshes=st.refactors, k=st.nodes)
+
+
 def solve_miqp(P, q, G, h, lb, ub, is_bin, **kw):
     """min 1/2 x'Px + q'x over the mixed-integer polytope (P symmetric PSD)"""
     P = np.ascontiguousarray(P, np.float64)
