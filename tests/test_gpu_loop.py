@@ -199,3 +199,56 @@ def test_staged_input_sets_equal_direct_uploads():
     with pytest.raises(gpu.MldGpuError):
         p.select(3)
     p.close(); m.close()
+
+
+def _fixed_pattern(ag, wl, p, d, rng, nb):
+    """random heater schedules with the grid binary consistent with the sign of the tie flow (as test_gpu_solve does)"""
+    bins = np.where(p.is_bin)[0]
+    nv = d["nu"] + d["ndelta"] + d["nz"] + d["nmu"]
+    isdelta = (bins % nv) == d["nu"]
+    fixed = np.zeros((nb, p.n_bin), dtype=np.uint8)
+    for s in range(nb):
+        om = ag["omega"][s].reshape(wl["N_tilde"], -1)
+        u = (rng.random((wl["N_tilde"], d["nu"])) < 0.2).astype(np.uint8)
+        y = u @ ag["params"]["P_h_Nom"] + om[:, -1]
+        fixed[s, ~isdelta] = u.ravel()
+        fixed[s, isdelta] = (y >= 0).astype(np.uint8)
+    return fixed
+
+
+@pytest.mark.parametrize("name,nb", [("cfg2", 48), ("cfg3", 96)])
+def test_lds_resident_lp_equals_dense_dictionary_lp(name, nb):
+    """relaxation-only mode (BASELINE configs[1]: binaries fixed): the LDS-resident revised dual simplex (k_lp_lds) against the
+    dense-dictionary kernel (opts.reserved bit 8) and the C oracle's LP on the same instances"""
+    import orc
+    import tighten_np
+    wl = syn.make_workload(name, batch=nb)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    m = gpu.GpuModel([ag["mats"]], d)
+    cost = host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"])
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost)
+    q = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost, reserved=256)
+    fixed = _fixed_pattern(ag, wl, p, d, np.random.Generator(np.random.PCG64(9)), nb)
+    a = p.solve(ag["x0"], ag["omega"], fixed_bin=fixed)
+    b = q.solve(ag["x0"], ag["omega"], fixed_bin=fixed)
+    assert np.array_equal(a["status"], b["status"]), (a["status"], b["status"])
+    ok = a["status"] == 0
+    assert ok.sum() >= nb // 2
+    assert np.all(np.abs(a["obj"][ok] - b["obj"][ok]) <= 1e-9 * np.maximum(1.0, np.abs(b["obj"][ok])))
+    assert np.all(a["nodes"] == 1)
+    bins = np.where(p.is_bin)[0]
+    assert np.array_equal(a["v"][:, bins][ok], fixed[ok].astype(float))
+    sf = cn.standard_form(tighten_np.tighten(ag["mats"], d, nu_l=d["nu_l"]), ag["atoms"], wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
+    for s in range(0, nb, 7):
+        lb, ub = sf["lb"].copy(), sf["ub"].copy()
+        lb[bins] = ub[bins] = fixed[s]
+        ref = orc.solve_milp(cn.lin_cost(sf["cost"], ag["x0"][s], ag["omega"][s]), sf["G"], cn.rhs(sf["evo"], ag["x0"][s], ag["omega"][s]), lb, ub,
+                             np.zeros_like(sf["is_bin"]), presolve=0, max_cuts=0, cut_rounds=0)
+        r = cn.cost_const(sf["cost"]["const_terms"], ag["x0"][s], ag["omega"][s])
+        assert gpu._lib.STATUS_NAMES[int(a["status"][s])] == ref["status"]
+        if ref["status"] == "optimal":
+            assert abs(a["obj"][s] - (ref["obj"] + r)) <= 1e-8 * max(1.0, abs(ref["obj"] + r))
+    print("%s: LDS LP %.3f ms (%.0f/s, %d pivots), dense %.3f ms (%.0f/s, %d pivots)" % (
+        name, a["stats"]["solve_ms"], nb / a["stats"]["solve_ms"] * 1e3, a["stats"]["pivots"], b["stats"]["solve_ms"], nb / b["stats"]["solve_ms"] * 1e3, b["stats"]["pivots"]))
+    p.close(); q.close(); m.close()
