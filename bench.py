@@ -383,6 +383,12 @@ def main():
         result["roofline_condense"] = {"kernel": "k_condense_model+k_condense_flat", "bound": "hbm", "achieved": round(ach, 1),
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                        "bytes_per_model": int(bytes_cond), "models": args.agents, "kernel_ms": round(ms, 4)}
+        ms32 = min(model.condense_device(N_t, f32=True) for _ in range(5))      # fp32 materialisation (mld_condense_f32): half the output bytes
+        bytes32 = 4.0 * N_t * (nc + nx + ny) * cols + 8.0 * ((nx + ny + nc) * (nx + nv + nw + 1) + nc * ny)
+        result["roofline_condense_f32"] = {"kernel": "k_condense_model+k_condense_flat<float>", "bound": "hbm", "achieved": round(args.agents * bytes32 / (ms32 * 1e-3) / 1e9, 1),
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(args.agents * bytes32 / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "bytes_per_model": int(bytes32), "models": args.agents, "kernel_ms": round(ms32, 4),
+                                           "speedup_vs_fp64_output": round(ms / ms32, 3)}
         try:        # HBM bytes of the two condensing launches from the same PMC passes (FETCH + WRITE, per launch of each kernel)
             allc = json.load(open(pmc)).get("all", {})
             kb = sum(allc.get(c, {}).get(k, {}).get("kb_per_launch", 0.0) for c in ("FETCH_SIZE", "WRITE_SIZE") for k in ("k_condense_model", "k_condense_flat"))

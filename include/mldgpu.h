@@ -138,6 +138,14 @@ int mld_condense(mld_model_t *, int N_tilde, int flags, double *Phi_x, double *G
                  double *Gamma_5, double *L_x, double *L_v, double *L_w, double *L_5, double *H_x, double *H_v,
                  double *H_w, double *H_5);
 
+/* fp32 materialisation (the MLD_F32 side of the condensing, SURVEY 8b / BASELINE configs[4] "fp32 condensing"): the same block
+ * arithmetic in fp64 (the block products have inner dimension nx <= 15: nothing for the matrix cores), every output element
+ * rounded once to fp32 on its way to HBM -- each value is the correctly rounded fp64 value, relative error <= 6e-8 -- so the
+ * write stream that bounds the kernel is half as long.  Time-invariant models only. */
+int mld_condense_device_f32(mld_model_t *, int N_tilde, int flags, double *kernel_ms);
+int mld_condense_f32(mld_model_t *, int N_tilde, int flags, float *Phi_x, float *Gamma_v, float *Gamma_w, float *Gamma_5, float *L_x,
+                     float *L_v, float *L_w, float *L_5, float *H_x, float *H_v, float *H_w, float *H_5);
+
 /* ---- problem ------------------------------------------------------------------------------
  * Replaces MpcController.build (controllers/mpc_controller.py:76-101): condensed constraint maps
  * (on device, from the big-M-tightened model), cost pull-back (kernel K4), scaling, bounds

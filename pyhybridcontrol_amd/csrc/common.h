@@ -54,6 +54,7 @@ struct mld_model {
     CondLayout lay;
     double *d_blocks;     // n_models x blk_stride
     double *d_out[12];    // materialised matrices, each n_models x out_size[k]
+    float *d_out32[12];   // the same in fp32 (mld_condense_f32), allocated on first use
     double *d_tvQ, *d_tvS; // time-varying horizons: products Q(i,j) (triangular) and the affine chain, written by k_tv_chain
 };
 
@@ -62,5 +63,5 @@ enum { MT_A = 0, MT_B1, MT_B2, MT_B3, MT_B4, MT_b5, MT_C, MT_D1, MT_D2, MT_D3, M
 // output order in d_out
 enum { O_PhiX = 0, O_GamV, O_GamW, O_Gam5, O_LX, O_LV, O_LW, O_L5, O_HX, O_HV, O_HW, O_H5 };
 
-int condense_model_device(mld_model *m, int N, double *kernel_ms, hipStream_t stream);
+int condense_model_device(mld_model *m, int N, double *kernel_ms, hipStream_t stream, bool f32 = false);
 void compute_layout(const mld_dims &d, int N, CondLayout *L);

@@ -90,7 +90,7 @@ static int model_create_impl(mld_model_t **out, const mld_dims *dims, int n_sets
     mld_model *m = new mld_model();
     m->dims = d; m->n_models = n_sets; m->tv_N = tv_N; m->nv = d.nu + d.ndelta + d.nz + d.nmu;
     m->cond_N = -1; m->d_blocks = nullptr; m->d_pack = nullptr; m->pack_len = 0; m->d_tvQ = m->d_tvS = nullptr;
-    for (int k = 0; k < 12; ++k) m->d_out[k] = nullptr;
+    for (int k = 0; k < 12; ++k) { m->d_out[k] = nullptr; m->d_out32[k] = nullptr; }
     m->h_mats.resize(20);
     for (int k = 0; k < 20; ++k) {
         int r, c; mat_shape(d, k, &r, &c);
@@ -156,6 +156,7 @@ int mld_model_destroy(mld_model_t *m)
     if (m->d_tvQ) (void)hipFree(m->d_tvQ);
     if (m->d_tvS) (void)hipFree(m->d_tvS);
     for (int k = 0; k < 12; ++k) if (m->d_out[k]) (void)hipFree(m->d_out[k]);
+    for (int k = 0; k < 12; ++k) if (m->d_out32[k]) (void)hipFree(m->d_out32[k]);
     delete m;
     return MLD_OK;
 }
@@ -177,6 +178,26 @@ int mld_condense(mld_model_t *m, int N_tilde, int flags, double *Phi_x, double *
     for (int k = 0; k < 12; ++k) {
         const size_t bytes = sizeof(double) * m->lay.out_size[k] * m->n_models;
         if (outs[k] && bytes) HIP_TRY(hipMemcpy(outs[k], m->d_out[k], bytes, hipMemcpyDeviceToHost));
+    }
+    return MLD_OK;
+}
+
+int mld_condense_device_f32(mld_model_t *m, int N_tilde, int flags, double *kernel_ms)
+{
+    (void)flags;
+    if (!m) { mld_set_error("null model"); return MLD_ERR_INVALID; }
+    return condense_model_device(m, N_tilde, kernel_ms, 0, true);
+}
+
+int mld_condense_f32(mld_model_t *m, int N_tilde, int flags, float *Phi_x, float *Gamma_v, float *Gamma_w, float *Gamma_5, float *L_x, float *L_v,
+                     float *L_w, float *L_5, float *H_x, float *H_v, float *H_w, float *H_5)
+{
+    int rc = mld_condense_device_f32(m, N_tilde, flags, nullptr);
+    if (rc) return rc;
+    float *outs[12] = {Phi_x, Gamma_v, Gamma_w, Gamma_5, L_x, L_v, L_w, L_5, H_x, H_v, H_w, H_5};
+    for (int k = 0; k < 12; ++k) {
+        const size_t bytes = sizeof(float) * m->lay.out_size[k] * m->n_models;
+        if (outs[k] && bytes) HIP_TRY(hipMemcpy(outs[k], m->d_out32[k], bytes, hipMemcpyDeviceToHost));
     }
     return MLD_OK;
 }

@@ -87,23 +87,25 @@ class GpuModel(object):
         except Exception:
             pass
 
-    def condense_device(self, N_tilde):
-        """run K1+K2 into device-resident buffers; returns kernel milliseconds (HIP events)"""
+    def condense_device(self, N_tilde, f32=False):
+        """run K1+K2 into device-resident buffers (fp32 materialisation with f32=True); returns kernel milliseconds (HIP events)"""
         ms = C.c_double()
-        check(_lib.load().mld_condense_device(self._h, int(N_tilde), 0, C.byref(ms)))
+        fn = _lib.load().mld_condense_device_f32 if f32 else _lib.load().mld_condense_device
+        check(fn(self._h, int(N_tilde), 0, C.byref(ms)))
         return ms.value
 
-    def condense(self, N_tilde, names=EVO_NAMES):
-        """materialised evolution matrices, dict name -> (n_models, rows, cols) arrays"""
+    def condense(self, N_tilde, names=EVO_NAMES, dtype=np.float64):
+        """materialised evolution matrices, dict name -> (n_models, rows, cols) arrays; dtype np.float32 = mld_condense_f32"""
         shapes = evo_shapes(self.dims, int(N_tilde))
+        f32 = np.dtype(dtype) == np.float32
         out, ptrs = {}, []
         for nm in EVO_NAMES:
             if nm in names:
-                out[nm] = np.zeros((self.n_models,) + shapes[nm])
-                ptrs.append(_lib.dptr(out[nm]))
+                out[nm] = np.zeros((self.n_models,) + shapes[nm], dtype=np.float32 if f32 else np.float64)
+                ptrs.append(out[nm].ctypes.data_as(C.POINTER(C.c_float)) if f32 else _lib.dptr(out[nm]))
             else:
                 ptrs.append(None)
-        check(_lib.load().mld_condense(self._h, int(N_tilde), 0, *ptrs))
+        check((_lib.load().mld_condense_f32 if f32 else _lib.load().mld_condense)(self._h, int(N_tilde), 0, *ptrs))
         return out
 
 

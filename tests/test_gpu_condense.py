@@ -45,3 +45,18 @@ def test_condense_gpu_batched_models_match_oracle():
     ms = m.condense_device(wl["N_tilde"])
     assert ms > 0
     m.close()
+
+
+@pytest.mark.parametrize("path", g.case_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_fp32_materialisation_is_the_rounded_fp64_result(path):
+    """mld_condense_f32 (MLD_F32 condensing, BASELINE configs[4]): every element is the fp64 value rounded once to fp32 -- bit-equal to
+    the fp64 output cast to float32 -- and within 1e-5 (relative to the matrix scale) of the reference-made golden fixtures"""
+    z, mats, dims, N_p, N_tilde = g.load_case(path)
+    m = gpu.GpuModel([mats], dims)
+    e64 = m.condense(N_tilde)
+    e32 = m.condense(N_tilde, dtype=np.float32)
+    for name in g.EVO_NAMES:
+        assert e32[name].dtype == np.float32 and e32[name].shape == e64[name].shape
+        assert np.array_equal(e32[name], e64[name].astype(np.float32)), name
+        g.check_evo(z, name, e32[name][0].astype(np.float64), dims, rtol=1e-5)
+    m.close()
