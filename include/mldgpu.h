@@ -78,7 +78,8 @@ typedef struct {
                               round).  Results are the same up to rounding with every bit; only speed and traces change.
                               bit6 first-fractional branching instead of penalty branching, bit7 K3 / K4 on the vector ALUs (k_rhs, k_gemm)
                               instead of the matrix cores, bit8 relaxation-only batches (every binary fixed) on the dense-dictionary kernel instead of
-                              the LDS-resident revised simplex (k_lp_lds). */
+                              the LDS-resident revised simplex (k_lp_lds), bit9 k_lp_lds with a working-basis capacity of 24 (its overflow fall-back to the
+                              dense kernel then takes most instances). */
 } mld_opts;
 
 /* Linear cost in tiled horizon form (the Python layer parses the reference's string-keyed atoms,

@@ -252,3 +252,44 @@ def test_lds_resident_lp_equals_dense_dictionary_lp(name, nb):
     print("%s: LDS LP %.3f ms (%.0f/s, %d pivots), dense %.3f ms (%.0f/s, %d pivots)" % (
         name, a["stats"]["solve_ms"], nb / a["stats"]["solve_ms"] * 1e3, a["stats"]["pivots"], b["stats"]["solve_ms"], nb / b["stats"]["solve_ms"] * 1e3, b["stats"]["pivots"]))
     p.close(); q.close(); m.close()
+
+
+def test_lds_lp_overflow_fallback_and_model_switching():
+    """k_lp_lds edge cases: (i) instances whose working basis outgrows the LDS capacity (forced: opts.reserved bit 9 caps it at 24) are
+    re-solved by the dense kernel and the batch still equals the all-dense result; (ii) several models interleaved in one batch
+    (the workgroup reloads the Toeplitz blocks on every model change); (iii) an infeasible LP keeps its status"""
+    wl = syn.make_workload("cfg3", batch=20, n_agents=3)
+    d = wl["agents"][0]["dims"]
+    N = wl["N_tilde"]
+    m = gpu.GpuModel([a["mats"] for a in wl["agents"]], d)
+    cost = host.stack_costs([host.cost_from_atoms(a["atoms"], d, wl["N_p"], N) for a in wl["agents"]])
+    x0 = np.concatenate([a["x0"] for a in wl["agents"]])
+    om = np.concatenate([a["omega"] for a in wl["agents"]])
+    midx = np.repeat(np.arange(3), 20).astype(np.int32)
+    order = np.random.Generator(np.random.PCG64(3)).permutation(60)
+    x0, om, midx = x0[order], om[order], midx[order]
+    ref_p = gpu.GpuProblem(m, wl["N_p"], N, cost, reserved=256)
+    fixed = np.concatenate([_fixed_pattern(a, wl, ref_p, d, np.random.Generator(np.random.PCG64(20 + i)), 20) for i, a in enumerate(wl["agents"])])[order]
+    ref = ref_p.solve(x0, om, midx, fixed_bin=fixed)
+    for flags in (0, 512):
+        p = gpu.GpuProblem(m, wl["N_p"], N, cost, reserved=flags)
+        out = p.solve(x0, om, midx, fixed_bin=fixed)
+        assert np.array_equal(out["status"], ref["status"]), flags
+        ok = ref["status"] == 0
+        assert ok.sum() >= 30
+        assert np.all(np.abs(out["obj"][ok] - ref["obj"][ok]) <= 1e-9 * np.maximum(1.0, np.abs(ref["obj"][ok]))), flags
+        if flags == 512:
+            assert (out["pivots"] != ref["pivots"]).sum() < 60          # (the fall-back instances ran on the dense kernel: same pivot counts there)
+        p.close()
+    ref_p.close(); m.close()
+    # (iii) an infeasible LP: hard bound 1 <= x <= ... contradiction (no soft slack), one binary input fixed
+    import pyhybridcontrol_amd as phc
+    hard = dict(A=[[1.0]], B1=[[0.0]], E=[[1.0], [-1.0]], F1=[[0.0], [0.0]], f5=[[1.0], [-2.0]])
+    dims = dict(nx=1, nu=1, ndelta=0, nz=0, nmu=0, nomega=0, ny=1, nc=2, nu_l=1, nmu_l=0)
+    gm = gpu.GpuModel([dict(hard, C=[[1.0]])], dims)
+    for flags in (0, 256):
+        gp = gpu.GpuProblem(gm, 7, 8, host.cost_from_atoms({"q_u": 1.0}, dims, 7, 8), reserved=flags)
+        o = gp.solve(np.zeros((2, 1)), np.zeros((2, 0)), fixed_bin=np.zeros((2, 8), np.uint8))
+        assert np.all(o["status"] == 1) and not np.isfinite(o["obj"]).any(), (flags, o["status"])
+        gp.close()
+    gm.close()
