@@ -1342,9 +1342,21 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                                     if (sa * t->rs[i] > 1e-6) feas = 0;
                                 }
                                 if (feas && ob < best) { best = ob; have = 1; memcpy(x_out, xo, sizeof(double) * n); }
-                                if (feas)   /* a free variable resting on the artificial box (+-ORC_BIG, scaled): no finite optimum */
+                                if (feas && t->P)   /* (QP relaxations: a free variable resting on the artificial box counts as no finite optimum) */
                                     for (int j = 0; j < n; ++j)
                                         if ((lb[j] == -INFINITY && xo[j] / t->cs[j] <= -0.999 * ORC_BIG) || (ub[j] == INFINITY && xo[j] / t->cs[j] >= 0.999 * ORC_BIG)) unbounded = 1;
+                                if (feas && !t->P) {
+                                    /* A free variable resting NON-BASIC on the artificial box (+-ORC_BIG) with a non-zero reduced cost: the value
+                                     * still falls along its ray -- no finite optimum.  With a zero reduced cost the box is only where a
+                                     * variable the objective does not depend on happens to sit: the optimum is finite (found by the fuzz
+                                     * test: a zero-cost auxiliary z whose column only relaxes the rows; round 1 called that unbounded). */
+                                    const double *dd = t->D + (size_t)t->mcap * t->ld;
+                                    for (int c = 0; c < n; ++c) {
+                                        const int j = t->nonbasic[c];
+                                        if (j >= n || fabs(dd[c]) <= 1e-9) continue;
+                                        if ((lb[j] == -INFINITY && t->xN[c] <= -0.999 * ORC_BIG) || (ub[j] == INFINITY && t->xN[c] >= 0.999 * ORC_BIG)) unbounded = 1;
+                                    }
+                                }
                                 leaf_ok = feas;
                             }
                             for (int k = 0; k < ns; ++k) set_bounds(t, sv_j[k], sv_lo[k], sv_hi[k]);
