@@ -13,7 +13,7 @@ device-to-device copy (mld_select_inputs), then K3 (right-hand sides, MFMA GEMM)
 gather of (objective, status, step-0 inputs) when N > 1.  One "MPC step" of the metric = one agent-solve.  The longest-first work
 queue is learnt from the PREVIOUS step, i.e. from different instances of the same agents.  After the timed region a closed-loop leg
 (mld_advance_batch: plant update with the inputs just computed, forecast shifted) reports how the rate moves when the population
-drifts to its steady state (tanks riding their lower temperature bound: harder instances than the synthetic distribution).
+drifts out of the seeded regime towards its steady state (harder instances than the synthetic distribution).
 
 No torch anywhere: ranks / addresses come from the environment `python -m torch.distributed.run` exports, the RCCL
 unique id travels over a small TCP side channel (pyhybridcontrol_amd.batch.TcpRendezvous).
@@ -376,8 +376,8 @@ def main():
             rates.append(round(world * n_local / t_c, 1))
             prov.append(round(st_c["n_optimal"] / n_local, 4))
         result["closed_loop"] = {"steps": args.closed_loop_steps, "value_per_step": rates, "proven_per_step": prov,
-                                 "note": "mld_advance_batch between solves (reference: sim_step_k -> lsim_k); the tanks settle on their lower temperature "
-                                         "bound, the instances get harder than the seeded distribution (DESIGN section 6)"}
+                                 "note": "mld_advance_batch between solves (reference: sim_step_k -> lsim_k); the population drifts out of the seeded regime "
+                                         "(x0 in 55..64: most tanks need no heating inside the horizon) and the instances get harder (DESIGN section 6)"}
     if rank == 0:
         # secondary roofline: condensing K1+K2 (SURVEY 8d formula: outputs + inputs), 64 models per launch
         ms = min(model.condense_device(N_t) for _ in range(5))
