@@ -28,7 +28,10 @@ for tag, flags in (("dense", 0), ("k_milp_lds", 1024 | extra)):
         from pyhybridcontrol_amd import _lib
         prof = (C.c_int64 * 8)(); _lib.load().mld_debug_profile(p._h, prof)
         t = np.array(list(prof), dtype=float); names = ["simplex", "refresh/verify", "penalties", "bound changes", "leaf", "cut derivation", "bookkeeping", "set-up"]
-        print("   phases (us per node): " + ", ".join("%s %.1f" % (nm, v / 100.0 / out["nodes"].sum()) for nm, v in zip(names, t)) + "; pivots per node %.2f" % (out["pivots"].sum() / out["nodes"].sum()))
+        if extra & 4096:
+            names = ["leaving", "rho", "pivot row", "ratio test", "entering column", "value updates", "W^-1 update", "outside pivots"]
+            print("   simplex phases (us per pivot): " + ", ".join("%s %.2f" % (nm, v / 100.0 / out["pivots"].sum()) for nm, v in zip(names, t)))
+        else: print("   phases (us per node): " + ", ".join("%s %.1f" % (nm, v / 100.0 / out["nodes"].sum()) for nm, v in zip(names, t)) + "; pivots per node %.2f" % (out["pivots"].sum() / out["nodes"].sum()))
         print("   status -1 (would fall back to the dense kernel; only visible with ML_FLAGS=2048): %d" % (out["status"] == -1).sum())
     p.close()
 a, b = res["dense"], res["k_milp_lds"]
