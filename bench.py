@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--exact-sample", type=int, default=-1, help="instances of the exact-gap leg (-1 = the whole shard, 0 = skip)")
     ap.add_argument("--closed-loop-steps", type=int, default=6, help="steps of the closed-loop leg after the timed region (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--reserved", type=int, default=0, help="diagnostics: opts.reserved bits for the solver (include/mldgpu.h), e.g. 1024 = the experimental LDS-resident branch-and-cut")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank rehearsal on ONE GPU: every rank on device 0, gather over the TCP side channel")
     return ap.parse_args()
 
@@ -216,7 +217,7 @@ def main():
     d = agents[0]["dims"]
     model = gpu.GpuModel([a["mats"] for a in agents], d)
     cost = host.stack_costs([host.cost_from_atoms(a["atoms"], d, N_p, N_t) for a in agents])
-    prob = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit)
+    prob = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit, reserved=args.reserved)
     n_local = x0.shape[0]
     exact = None
     if world == 1 and args.exact_sample != 0:
@@ -350,7 +351,7 @@ def main():
         result["value_exact"] = exact["value_exact"]
         result["exact"] = exact
     # the same loop without the learnt longest-first queue (opts.reserved bit 3): one more step on the next instance set
-    prob.set_opts(reserved=8)
+    prob.set_opts(reserved=8 | args.reserved)
     sync()
     t0 = time.perf_counter()
     st_nl = step()
@@ -358,7 +359,7 @@ def main():
     t_nl = time.perf_counter() - t0
     if rd is not None:
         t_nl = rd.all_max(t_nl)
-    prob.set_opts(reserved=0)
+    prob.set_opts(reserved=args.reserved)
     result["work_queue"] = {"value_learnt_order": result["value"], "value_fifo_order": round(world * n_local / t_nl, 2),
                             "note": "longest-first order learnt from the previous step (other scenarios of the same agents) vs plain instance order (one extra step)",
                             "kernel_ms_fifo": round(float(st_nl["solve_ms"]), 1)}

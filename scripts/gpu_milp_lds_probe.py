@@ -8,13 +8,14 @@ nb = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 max_nodes = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
 gap_rel = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 extra = int(os.environ.get("ML_FLAGS", "0"))
+kw_all = dict(cut_rounds=int(os.environ["ML_CUT_ROUNDS"])) if "ML_CUT_ROUNDS" in os.environ else {}
 kw_dense = dict(mir_per_round=int(os.environ["ML_DENSE_MIR"])) if "ML_DENSE_MIR" in os.environ else {}
 wl = syn.make_workload(name, batch=nb); ag = wl["agents"][0]; d = ag["dims"]
 m = gpu.GpuModel([ag["mats"]], d)
 cost = host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"])
 res = {}
 for tag, flags in (("dense", 0), ("k_milp_lds", 1024 | extra)):
-    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost, reserved=flags, max_nodes=max_nodes, gap_rel=gap_rel, gap_abs=1e-9 if gap_rel == 0 else 0.0, **(kw_dense if tag == "dense" else {}))
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost, reserved=flags, max_nodes=max_nodes, gap_rel=gap_rel, gap_abs=1e-9 if gap_rel == 0 else 0.0, **kw_all, **(kw_dense if tag == "dense" else {}))
     p.upload(ag["x0"], ag["omega"])
     t0 = time.time(); st = p.solve_resident(); wall = time.time() - t0
     out = p.download(); tel = p.telemetry()
