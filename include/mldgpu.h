@@ -79,7 +79,11 @@ typedef struct {
                               bit6 first-fractional branching instead of penalty branching, bit7 K3 / K4 on the vector ALUs (k_rhs, k_gemm)
                               instead of the matrix cores, bit8 relaxation-only batches (every binary fixed) on the dense-dictionary kernel instead of
                               the LDS-resident revised simplex (k_lp_lds), bit9 k_lp_lds with a working-basis capacity of 24 (its overflow fall-back to the
-                              dense kernel then takes most instances). */
+                              dense kernel then takes most instances; the same cap applies to k_milp_lds),
+                              bit10 EXPERIMENTAL: mixed-integer batches (linear cost, time-invariant models that fit) on the LDS-resident branch-and-cut
+                              k_milp_lds (csrc/milp_lds.inc) instead of the dense-dictionary kernel; instances it cannot finish are
+                              re-solved by the dense kernel in the same call, bit11 leave those instances at status -1 instead (counting only),
+                              bit12 k_milp_lds profile slots = phases inside the simplex (mld_debug_profile). */
 } mld_opts;
 
 /* Linear cost in tiled horizon form (the Python layer parses the reference's string-keyed atoms,
