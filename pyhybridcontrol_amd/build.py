@@ -24,7 +24,7 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
            "-Wno-unused-result"] + os.environ.get("MLD_CXXFLAGS", "").split() + ["-o", OUT, SRC, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
