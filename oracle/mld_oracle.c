@@ -899,10 +899,13 @@ static int gmi_round(dict_t *t, int max_cuts)
         const double f0 = t->xB[r] - floor(t->xB[r]);
         const double *row = t->D + (size_t)r * ld;
         double gmin = INFINITY, gmax = 0;
+        int unsafe = 0;
         for (int c = 0; c < n; ++c) {
             const int j = t->nonbasic[c];
             double a = (t->lo[j] == t->hi[j]) ? 0.0 : (t->at_upper[c] ? -row[c] : row[c]);
-            if (fabs(a) < ORC_COEF_ZERO) a = 0.0;
+            /* round-off sized coefficients are dropped; that strengthens the cut by |a| t_j, which is only harmless when t_j is O(1): a free
+             * variable resting on the artificial box (t_j up to 2e7) makes the cut unsafe -- it is not derived (gmin = 0 fails the range test) */
+            if (fabs(a) < ORC_COEF_ZERO) { if (a != 0.0 && j < n && fabs(t->at_upper[c] ? t->hi[j] : t->lo[j]) >= 0.5 * ORC_BIG) unsafe = 1; a = 0.0; }
             double gc;
             if (j < n && t->is_int[j]) {
                 double fj = a - floor(a);
@@ -912,7 +915,7 @@ static int gmi_round(dict_t *t, int max_cuts)
             g[c] = gc;
             if (gc > 0) { if (gc < gmin) gmin = gc; if (gc > gmax) gmax = gc; }
         }
-        if (gmax <= 0 || gmax / gmin > 1e6) continue;
+        if (unsafe || gmax <= 0 || gmax / gmin > 1e6) continue;
         /* sum_c g_c t_c >= 1  over structural variables:  ax.x <= bx */
         for (int j = 0; j < n; ++j) ax[j] = 0;
         double bx = -1.0;
