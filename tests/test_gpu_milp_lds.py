@@ -106,3 +106,41 @@ def test_lds_branch_and_cut_overflow_falls_back_to_dense():
     assert np.all(out["obj"][over] == ref["obj"][over]), "re-solved instances are the dense kernel's results, bit for bit"
     assert np.all(np.abs(out["obj"] - ref["obj"]) <= 2e-4 * np.maximum(1.0, np.abs(ref["obj"])))
     m.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_lds_branch_and_cut_on_random_mld_models_matches_highs(seed):
+    """models that are NOT the tank clusters (tests/test_gpu_fuzz.py: random couplings, free auxiliaries, short horizon): the LDS engine's
+    compact lag-block store, step buckets, cuts and search against scipy's HiGHS on the original rows; UNBOUNDED must be reported too"""
+    from scipy.optimize import Bounds, LinearConstraint, milp
+    import condense_np as cn
+    from test_gpu_fuzz import random_mld
+    mats, dims, atoms, rng = random_mld(seed)
+    N_p, N, nb = 4, 5, 6
+    x0 = rng.standard_normal((nb, dims["nx"]))
+    om = rng.standard_normal((nb, N * dims["nomega"]))
+    m = gpu.GpuModel([mats], dims)
+    cost = host.cost_from_atoms(atoms, dims, N_p, N)
+    raw_out = gpu.GpuProblem(m, N_p, N, cost, max_nodes=50000, max_pivots=400000, reserved=LDS | SHOW_FALLBACK).solve(x0, om)
+    out = gpu.GpuProblem(m, N_p, N, cost, max_nodes=50000, max_pivots=400000, reserved=LDS).solve(x0, om)
+    m.close()
+    raw = cn.standard_form(mats, atoms, N_p, N, nu_l=dims["nu_l"])
+    own = 0
+    for s in range(nb):
+        w = om[s] if dims["nomega"] else np.zeros(0)
+        h, q = cn.rhs(raw["evo"], x0[s], w), cn.lin_cost(raw["cost"], x0[s], w)
+        r = cn.cost_const(raw["cost"]["const_terms"], x0[s], w)
+        ref = milp(q, constraints=LinearConstraint(raw["G"], -np.inf, h), integrality=raw["is_bin"].astype(int),
+                   bounds=Bounds(raw["lb"], raw["ub"]), options=dict(mip_rel_gap=0.0))
+        own += int(raw_out["status"][s] != -1)
+        if ref.status == 3:
+            assert out["status"][s] == 4, (seed, s, out["status"][s], raw_out["status"][s])
+            continue
+        assert ref.status == 0, (seed, s, ref.status)
+        assert out["status"][s] == 0, (seed, s, out["status"][s], raw_out["status"][s], out["nodes"][s])
+        assert abs(out["obj"][s] - (ref.fun + r)) <= 1e-6 * max(1.0, abs(ref.fun + r)), (seed, s, out["obj"][s], ref.fun + r, raw_out["status"][s])
+        v = out["v"][s]
+        bins = raw["is_bin"]
+        assert np.all((v[bins] == 0) | (v[bins] == 1))
+        assert np.all(raw["G"] @ v - h <= 1e-6 * np.maximum(1.0, np.abs(raw["G"]).max(axis=1)))
+    print("seed %d: %d of %d instances finished by k_milp_lds itself" % (seed, own, nb))
