@@ -249,7 +249,18 @@ typedef struct {
     const double *P;      /* scaled Hessian n x n (NULL = linear cost) */
     double *Y, *PY, *Hm, *cm, *wm, *gcost, *vcur, *Pv;
     int pmax, qp_iters;
+    int *partner;         /* study only (ORC_ELASTIC_STATS): row of the soft constraint a singleton penalty column belongs to, or -1 */
 } dict_t;
+
+/* ---- study: what implicit soft-constraint slacks would save.  A penalty column mu_i appears in ONE row with a negative
+ * coefficient (E x + ... - mu_i <= f_i, cost c_i >= 0, mu_i >= 0): it and the row's slack s_i are never both basic, their dictionary
+ * columns are negatives of each other when both are non-basic, and while exactly one of them is basic the other's column is a unit vector
+ * (entry in the partner's row only, reduced cost exactly c_i) -- it needs no storage, and a pivot that exchanges the two partners touches
+ * one row.  Counted per pivot when ORC_ELASTIC_STATS is set: pivots, partner-exchange pivots, penalty columns with an implicit (unit)
+ * column, penalty columns whose partner is non-basic too (stored once for the pair), penalty columns in the model. */
+static double g_el[5];
+static int g_el_on = -1;
+void orc_elastic_stats(double out[5]) { for (int k = 0; k < 5; ++k) { out[k] = g_el[k]; g_el[k] = 0.0; } }
 
 static double *dalloc(size_t k) { return (double *)calloc(k + 1, sizeof(double)); }
 
@@ -392,6 +403,19 @@ static void pivot(dict_t *t, int r, int c, double leave_value)
         }
     }
     const int jb = t->basic[r], jn = t->nonbasic[c];
+    if (t->partner) {
+        double cheap = 0.0, implicit = 0.0, both = 0.0, pairs = 0.0;
+        if (jn < n && t->partner[jn] >= 0 && jb == n + t->partner[jn]) cheap = 1.0;
+        if (jb < n && t->partner[jb] >= 0 && jn == n + t->partner[jb]) cheap = 1.0;
+        for (int j = 0; j < n; ++j) {
+            if (t->partner[j] < 0) continue;
+            pairs += 1.0;
+            const int bj = t->where[j] < 0, bs = t->where[n + t->partner[j]] < 0;
+            if (bj != bs) implicit += 1.0; else if (!bj) both += 1.0;
+        }
+#pragma omp critical(orc_elastic)
+        { g_el[0] += 1.0; g_el[1] += cheap; g_el[2] += implicit; g_el[3] += both; g_el[4] += pairs; }
+    }
     t->basic[r] = jn; t->nonbasic[c] = jb;
     t->where[jn] = -1 - r; t->where[jb] = c;
     t->xB[r] = enter_val;
@@ -1138,6 +1162,15 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
         t->gcost = dalloc(n); t->vcur = dalloc(n); t->Pv = dalloc(n);
     }
     for (int i = 0; i < t->mcap; ++i) { t->lo[n + i] = 0; t->hi[n + i] = INFINITY; }
+    if (g_el_on < 0) g_el_on = getenv("ORC_ELASTIC_STATS") != NULL;
+    if (g_el_on && !Pq) {      /* study: singleton penalty columns and their rows */
+        t->partner = (int *)calloc(n + 1, sizeof(int));
+        for (int j = 0; j < n; ++j) {
+            int cnt = 0, row = -1; double v = 0.0;
+            for (int i = 0; i < m; ++i) if (G[(size_t)i * n + j] != 0.0) { cnt++; row = i; v = G[(size_t)i * n + j]; }
+            t->partner[j] = (cnt == 1 && v < 0.0 && !is_bin[j] && lb[j] == 0.0 && ub[j] == INFINITY && q[j] >= 0.0) ? row : -1;
+        }
+    }
     mark_dead(t, m, Pq == NULL);
     reset_dictionary(t);
     for (int c = 0; c < n; ++c) place(t, c);
@@ -1470,7 +1503,7 @@ done:
     *obj_out = have ? best : INFINITY;
     free(lb); free(ub); free(t->D); free(t->Gx); free(t->hx); free(t->q); free(t->rs); free(t->cs); free(t->lo);
     free(t->hi); free(t->xB); free(t->xN); free(t->basic); free(t->nonbasic); free(t->where); free(t->at_upper);
-    free(t->is_int); free(t->skip); free(t->tmp_col); free(t->tmp_row); free(t->dw); free(bins); free(root_lo); free(root_hi);
+    free(t->is_int); free(t->skip); free(t->tmp_col); free(t->tmp_row); free(t->dw); free(t->partner); free(bins); free(root_lo); free(root_hi);
     free(xs); free(xo); free(stk_j); free(stk_first); free(stk_second); free(sv_j); free(sv_lo); free(sv_hi);
     return status;
 }
