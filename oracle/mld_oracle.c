@@ -504,7 +504,7 @@ static void refactor(dict_t *t)
     free(want); free(rowfree); free(val); free(up);
 }
 
-static int dual_simplex(dict_t *t, double cutoff)
+static int dual_simplex_impl(dict_t *t, double cutoff)
 {
     const int n = t->n, ld = t->ld;
     const int m = t->m;
@@ -619,6 +619,22 @@ static int dual_simplex(dict_t *t, double cutoff)
 #define SD_PMAX 32
 
 /* reduced costs of the current basis for structural cost vector `cost` (slacks cost nothing) */
+/* a single re-solve that needs more than four times the problem's size in pivots is cycling (the Harris tolerances void Bland's guarantee):
+ * the dictionary is rebuilt from the original rows and the solve gets one more allowance (csrc/problem.inc s_dual_simplex) */
+static int dual_simplex(dict_t *t, double cutoff)
+{
+    const long cap = 4L * (t->m0 + t->n) + 1000, save = t->max_pivots;
+    t->max_pivots = save < t->pivots + cap ? save : t->pivots + cap;
+    int st = dual_simplex_impl(t, cutoff);
+    if (st == LP_ITERLIMIT && t->pivots < save) {
+        refactor(t);
+        t->max_pivots = save < t->pivots + cap ? save : t->pivots + cap;
+        st = dual_simplex_impl(t, cutoff);
+    }
+    t->max_pivots = save;
+    return st;
+}
+
 static void reprice(dict_t *t, const double *cost)
 {
     const int n = t->n, ld = t->ld;
@@ -1277,7 +1293,7 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                 const double cut = fmin(T, inc_cut);
                 double node_obj = INFINITY;
                 lp = dual_simplex(t, cut + 1e-12);
-                if (getenv("ORC_DEBUG")) fprintf(stderr, "node %d ph %d depth %d lp=%d obj=%.12g cut=%.12g T=%.12g\n", nodes, phase, depth, lp, objective(t), cut, T);
+                if (getenv("ORC_DEBUG")) fprintf(stderr, "node %d ph %d depth %d lp=%d obj=%.12g cut=%.12g T=%.12g pivots=%ld\n", nodes, phase, depth, lp, objective(t), cut, T, t->pivots);
                 if (lp == LP_ITERLIMIT) limit = 1;
                 else if (lp == LP_OPTIMAL || lp == LP_CUTOFF) {
                     double obj = objective(t);       /* LP(q) value: a valid bound also when P is PSD */
