@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--exact-sample", type=int, default=-1, help="instances of the exact-gap leg (-1 = the whole shard, 0 = skip)")
     ap.add_argument("--closed-loop-steps", type=int, default=6, help="steps of the closed-loop leg after the timed region (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--handles", type=int, default=2, help="problem handles (each with its own HIP stream and workspace) the timed steps alternate over: "
+                    "the workgroups of step k+1 move onto the CUs the stragglers of step k leave idle; 1 = one step after another")
+    ap.add_argument("--reference-steps", type=int, default=2, help="steps solved strictly one after another after the timed region (roofline, latency, value_one_at_a_time)")
     ap.add_argument("--reserved", type=int, default=0, help="diagnostics: opts.reserved bits for the solver (include/mldgpu.h), e.g. 1024 = the experimental LDS-resident branch-and-cut")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank rehearsal on ONE GPU: every rank on device 0, gather over the TCP side channel")
     return ap.parse_args()
@@ -225,7 +228,7 @@ def main():
     prob.upload(x0, om, midx)                       # inputs resident in HBM before the timed region
     # fresh scenario sets for every step (set 0 = the shard's own scenarios), all resident in HBM before the timed region
     from pyhybridcontrol_amd import synthetic as syn
-    n_sets = args.warmup + args.steps + 1
+    n_sets = args.warmup + args.steps + max(1, args.reference_steps) + 2
     x0_sets = np.empty((n_sets,) + x0.shape)
     om_sets = np.empty((n_sets,) + om.shape)
     x0_sets[0], om_sets[0] = x0, om
@@ -233,6 +236,16 @@ def main():
         rng = np.random.Generator(np.random.PCG64([syn.CONFIGS["cfg4"]["seed"], 7919, rank, t]))
         x0_sets[t], om_sets[t] = syn.make_scenarios(d["nx"], N_t, n_local, rng)
     prob.stage(x0_sets, om_sets)
+    # the timed steps alternate over `handles` problem handles on their own HIP streams (consecutive steps are independent scenario sets)
+    H = max(1, args.handles)
+    probs = [prob]
+    for _ in range(1, H):
+        q = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit, reserved=args.reserved)
+        q.upload(x0, om, midx); q.stage(x0_sets, om_sets)
+        probs.append(q)
+    if H > 1:
+        for q in probs:
+            q.use_stream()
     del x0_sets, om_sets
     gatherer = None
     if world > 1:
@@ -264,15 +277,42 @@ def main():
             gatherer.gather_results(prob)
         return st
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(count):
+        """`count` steps over the handles: step j is launched on handle j % H as soon as that handle's previous step has been finished
+        (statistics, learnt queue order, result gather); returns the per-step statistics once every step has finished"""
+        if H == 1:
+            return [step() for _ in range(count)]
+        res, pending = [None] * count, [None] * H
+        for j in range(count + H):
+            q = probs[j % H]
+            if pending[j % H] is not None:
+                res[pending[j % H]] = q.finish()
+                if gatherer is not None:
+                    gatherer.gather_results(q)
+                pending[j % H] = None
+            if j < count:
+                q.select(state["k"] % n_sets)
+                state["k"] += 1
+                q.launch()
+                pending[j % H] = j
+        return res
+
+    run_steps(args.warmup)
     sync()
     t0 = time.perf_counter()
-    stats = [step() for _ in range(args.steps)]
+    stats_timed = run_steps(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     if rd is not None:
         elapsed = rd.all_max(elapsed)
+    # reference: the same kind of step strictly one after another on one handle (clean per-kernel timing for the roofline, latency telemetry)
+    sync()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(max(1, args.reference_steps))]
+    sync()
+    elapsed_ref = time.perf_counter() - t0
+    if rd is not None:
+        elapsed_ref = rd.all_max(elapsed_ref)
     # ---- roofline of the dominant kernel (k_solve) on the LAST timed step: bytes its rank-1 dictionary updates streamed / its HIP-event time
     t0 = time.perf_counter()
     out = prob.download()
@@ -315,21 +355,23 @@ def main():
         "config": {"workload": "BASELINE cfg4 shard: %d agents x %d scenarios per GPU (n_h=7, N_p=24: n=575, 200 binaries, m=500), "
                                "full branch-and-cut MILP, MIPGap=%g, NodeLimit=%d, IterationLimit=%d; every step solves a fresh, independently seeded "
                                "scenario set of the same distribution" % (args.agents, args.scenarios, args.mip_gap, args.node_limit, args.pivot_limit),
-                   "timed_region": "K x (mld_select_inputs [D2D copy of the next staged scenario set] + mld_solve_resident [K3 + K5/K6] (+ RCCL gather of "
-                                   "(obj, status, step-0 inputs) from device buffers when N > 1)); all inputs were staged in HBM before the region, results stay "
-                                   "in HBM; the host download of the full results is outside (download_ms)",
+                   "timed_region": "K x (mld_select_inputs [D2D copy of the next staged scenario set] + mld_solve_launch / mld_solve_finish [K3 + K5/K6] (+ RCCL gather of "
+                                   "(obj, status, step-0 inputs) from device buffers when N > 1)), the steps alternating over %d problem handles on their own HIP "
+                                   "streams: step k+1 is queued while step k runs, so its workgroups take the CUs the stragglers of step k leave idle (results are "
+                                   "bit-identical to one-at-a-time solves); all inputs were staged in HBM before the region, results stay in HBM; the host "
+                                   "download of the full results is outside (download_ms)" % H,
                    "instances_per_gpu": n_local, "microgrid_steps_per_s": round(world * n_local * args.steps / elapsed / args.agents, 3),
                    "p50_solve_latency_ms": round(float(lat[len(lat) // 2]), 3), "p99_solve_latency_ms": round(float(lat[int(len(lat) * 0.99)]), 3),
                    "status_last_step": {"optimal": int((status == 0).sum()), "infeasible": int((status == 1).sum()), "node_limit": int(lim.sum()),
                                         "numerical": int((status == 3).sum()), "unbounded": int((status == 4).sum())},
-                   "status_per_step": [hist(s) for s in stats],
-                   "proven_fraction": round(float(np.mean([s["n_optimal"] for s in stats]) / n_local), 5),
+                   "status_per_step": [hist(s) for s in stats_timed],
+                   "proven_fraction": round(float(np.mean([s["n_optimal"] for s in stats_timed]) / n_local), 5),
                    "no_incumbent": int((~fin).sum()),
                    "gap_of_limited": ({"median": round(float(np.nanmedian(gap[lim])), 5), "p90": round(float(np.nanpercentile(gap[lim], 90)), 5),
                                        "max": round(float(np.nanmax(gap[lim])), 5)} if lim.any() else None),
                    "nodes_per_instance": round(float(out["nodes"].mean()), 1), "pivots_per_instance": round(pivots / n_local, 1),
                    "pivots_per_s": round(pivots / (kernel_ms * 1e-3)), "rhs_ms": round(float(np.mean([s["rhs_ms"] for s in stats])), 3),
-                   "kernel_ms_per_step": [round(float(s["solve_ms"]), 1) for s in stats],
+                   "kernel_ms_per_step_reference": [round(float(s["solve_ms"]), 1) for s in stats],
                    "download_ms": round(download_ms, 2),
                    "result_gather": (None if gatherer is None else type(gatherer).__name__)},
         "roofline": {"kernel": "k_solve", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -337,7 +379,13 @@ def main():
                      "algorithmic_bytes_per_launch": int(upd_bytes), "bytes_per_instance": int(upd_bytes / n_local),
                      "io_minimum_bytes_per_launch": int(io_bytes), "algorithmic_over_io_minimum": round(upd_bytes / io_bytes, 1),
                      "traffic_over_io_minimum": (round(traffic / io_bytes, 1) if traffic else None),
-                     "kernel_ms": round(kernel_ms, 3), "measured_on": "last timed step (HIP events around k_solve on the launch stream)"},
+                     "kernel_ms": round(kernel_ms, 3), "measured_on": "last reference step after the timed region (one launch at a time: HIP events around k_solve on "
+                                                                    "the launch stream; in the timed region the launches overlap)"},
+        "pipeline": {"handles": H, "value_one_at_a_time": round(world * n_local * len(stats) / elapsed_ref, 2), "ms_per_step_one_at_a_time": round(elapsed_ref / len(stats) * 1e3, 2),
+                     "reference_steps": len(stats),
+                     "note": "value: K timed steps alternating over the handles (mld_solve_launch / mld_solve_finish on per-problem HIP streams); value_one_at_a_time: "
+                             "the following steps with mld_solve_resident on one handle -- the difference is the ragged end of a step (0.5-1.2 s node-limited "
+                             "instances at random positions of the work queue) that the next step's workgroups fill"},
     }
     # K3 on the matrix cores: one [m0 x (nx + N nw)] . [(nx + N nw) x instances-of-the-model] GEMM per model
     rhs_ms = float(np.mean([s["rhs_ms"] for s in stats]))
@@ -360,8 +408,8 @@ def main():
     if rd is not None:
         t_nl = rd.all_max(t_nl)
     prob.set_opts(reserved=args.reserved)
-    result["work_queue"] = {"value_learnt_order": result["value"], "value_fifo_order": round(world * n_local / t_nl, 2),
-                            "note": "longest-first order learnt from the previous step (other scenarios of the same agents) vs plain instance order (one extra step)",
+    result["work_queue"] = {"value_learnt_order": result["pipeline"]["value_one_at_a_time"], "value_fifo_order": round(world * n_local / t_nl, 2),
+                            "note": "one launch at a time: longest-first order learnt from the previous step (other scenarios of the same agents) vs plain instance order (one extra step)",
                             "kernel_ms_fifo": round(float(st_nl["solve_ms"]), 1)}
     if args.closed_loop_steps > 0:
         # closed loop: the SAME scenarios advanced step by step (plant update with the inputs just computed, forecast shifted)

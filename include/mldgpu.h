@@ -190,6 +190,15 @@ int mld_upload_batch(mld_problem_t *, int batch, const int32_t *model_idx, const
  * next mld_upload_batch; n_cols = 0 clears. */
 int mld_upload_constraint_blocks(mld_problem_t *, int n_cols, const double *omega_cols, const int32_t *col_rows);
 int mld_solve_resident(mld_problem_t *, mld_stats *stats_out);
+
+/* The resident solve in two halves, for callers that keep several problems busy (a fleet of independent microgrids: the reference solves
+ * them one after another, controllers/controller_base.py:509).  mld_problem_use_stream gives the problem its own HIP stream;
+ * mld_solve_launch queues K3 + K5/K6 on it and returns; mld_solve_finish waits, reports the statistics and learns the work-queue order.
+ * While one problem's stragglers finish, the workgroups of the next problem's launch move onto the freed CUs.  Results are those of
+ * mld_solve_resident, bit for bit.  (Batches on the LDS-resident kernels complete inside mld_solve_launch.) */
+int mld_problem_use_stream(mld_problem_t *p);
+int mld_solve_launch(mld_problem_t *p);
+int mld_solve_finish(mld_problem_t *p, mld_stats *stats_out);
 int mld_download_results(mld_problem_t *, double *v_out, double *obj_out, int32_t *status_out,
                          double *lower_bound_out, int32_t *nodes_out, int32_t *pivots_out);
 

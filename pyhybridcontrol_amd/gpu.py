@@ -258,6 +258,20 @@ class GpuProblem(object):
         check(_lib.load().mld_solve_resident(self._h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in _lib.Stats._fields_}
 
+    def use_stream(self):
+        """give this problem its own HIP stream (launch / finish of several problems then overlap on the device)"""
+        check(_lib.load().mld_problem_use_stream(self._h))
+
+    def launch(self):
+        """queue K3 + K5/K6 for the resident batch and return (mld_solve_launch)"""
+        check(_lib.load().mld_solve_launch(self._h))
+
+    def finish(self):
+        """wait for the launched solve; statistics as solve_resident (mld_solve_finish)"""
+        st = _lib.Stats()
+        check(_lib.load().mld_solve_finish(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in _lib.Stats._fields_}
+
     def download(self):
         b = self.batch
         v, obj, lbnd = np.zeros((b, self.n)), np.zeros(b), np.zeros(b)

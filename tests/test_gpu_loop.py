@@ -293,3 +293,52 @@ def test_lds_lp_overflow_fallback_and_model_switching():
         assert np.all(o["status"] == 1) and not np.isfinite(o["obj"]).any(), (flags, o["status"])
         gp.close()
     gm.close()
+
+
+def test_launch_finish_on_two_streams_equals_resident_solves():
+    """mld_solve_launch / mld_solve_finish on two problem handles with their own HIP streams (bench.py's timed loop: step k+1 is queued while
+    step k runs) return, step by step, exactly what mld_solve_resident returns on one handle: objectives, statuses, inputs, node counts"""
+    nb, K = 96, 5
+    wl = syn.make_workload("cfg3", batch=nb)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    m = gpu.GpuModel([ag["mats"]], d)
+    cost = host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"])
+    rng = np.random.Generator(np.random.PCG64(77))
+    X = np.stack([ag["x0"]] + [ag["x0"] + 0.5 * rng.standard_normal(ag["x0"].shape) for _ in range(K)])
+    W = np.stack([ag["omega"]] + [ag["omega"] * (1.0 + 0.05 * rng.standard_normal(ag["omega"].shape)) for _ in range(K)])
+    kw = dict(gap_rel=1e-3, max_nodes=400, max_pivots=40000)
+    ref_p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost, **kw)
+    ref_p.upload(X[0], W[0]); ref_p.stage(X, W)
+    ref = []
+    for k in range(1, K + 1):
+        ref_p.select(k); st = ref_p.solve_resident(); out = ref_p.download()
+        ref.append((st["nodes"], st["pivots"], out["obj"].copy(), out["status"].copy(), out["v"].copy()))
+    probs = [gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost, **kw) for _ in range(2)]
+    for p in probs:
+        p.upload(X[0], W[0]); p.stage(X, W); p.use_stream()
+    got = [None] * K
+
+    def collect(p, k):
+        st = p.finish(); out = p.download()
+        got[k - 1] = (st["nodes"], st["pivots"], out["obj"].copy(), out["status"].copy(), out["v"].copy())
+
+    for k in range(1, K + 1):
+        p = probs[k % 2]
+        if k > 2:
+            collect(p, k - 2)
+        p.select(k); p.launch()
+    for k in (K - 1, K):
+        collect(probs[k % 2], k)
+    for k in range(K):
+        assert ref[k][0] == got[k][0] and ref[k][1] == got[k][1], (k, ref[k][:2], got[k][:2])
+        assert np.array_equal(ref[k][3], got[k][3]) and np.array_equal(ref[k][2], got[k][2]) and np.array_equal(ref[k][4], got[k][4])
+    with pytest.raises(Exception):
+        probs[0].finish()               # nothing in flight any more
+    probs[0].launch()
+    with pytest.raises(Exception):
+        probs[0].launch()               # the previous launch has not been finished
+    probs[0].finish()
+    for p in probs + [ref_p]:
+        p.close()
+    m.close()
