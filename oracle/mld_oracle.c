@@ -42,6 +42,7 @@
 #define ORC_PIV_TINY 1e-5
 #define ORC_INTTOL 1e-6
 #define ORC_COEF_ZERO 1e-9
+#define ORC_PURGE_SLACK 1e-3
 #define ORC_RESID_TOL 1e-6
 #ifndef ORC_PEN_DEFAULT
 #define ORC_PEN_DEFAULT 1
@@ -1233,6 +1234,9 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                 if (lp != LP_OPTIMAL) { root_ok = 0; break; }
                 if (objective(t) - before < 1e-6 * fmax(1.0, fabs(before))) { if (++stalled >= 2) break; } else stalled = 0;
             }
+            /* cut rows whose slack still sits basic in its own row (the cut never had to leave) and is clearly positive when the cut loop ends
+             * are not maintained below the root (csrc/problem.inc, same rule): dropping a cut is always valid, and the pivots get cheaper */
+            if (root_ok && !t->P) for (int i = m; i < t->m; ++i) if (t->basic[i] == n + i && t->xB[i] > ORC_PURGE_SLACK) t->skip[i] |= 2;
         }
     }
     if (!root_ok) { status = ORC_NUMERICAL; goto done; }
