@@ -338,7 +338,12 @@ def test_launch_finish_on_two_streams_equals_resident_solves():
     probs[0].launch()
     with pytest.raises(Exception):
         probs[0].launch()               # the previous launch has not been finished
+    with pytest.raises(Exception):
+        probs[0].download()             # ... and owns the buffers until it is
+    with pytest.raises(Exception):
+        probs[0].select(1)
     probs[0].finish()
+    probs[0].download()
     for p in probs + [ref_p]:
         p.close()
     m.close()
