@@ -383,9 +383,11 @@ def main():
                                                                     "the launch stream; in the timed region the launches overlap)"},
         "pipeline": {"handles": H, "value_one_at_a_time": round(world * n_local * len(stats) / elapsed_ref, 2), "ms_per_step_one_at_a_time": round(elapsed_ref / len(stats) * 1e3, 2),
                      "reference_steps": len(stats),
+                     "value_no_idle_bound": round(world * n_local / (float(tel["latency_ns"].sum()) * 1e-9 / max(1, _lib.device_info()["n_cu"])), 2),
                      "note": "value: K timed steps alternating over the handles (mld_solve_launch / mld_solve_finish on per-problem HIP streams); value_one_at_a_time: "
                              "the following steps with mld_solve_resident on one handle -- the difference is the ragged end of a step (0.5-1.2 s node-limited "
-                             "instances at random positions of the work queue) that the next step's workgroups fill"},
+                             "instances at random positions of the work queue) that the next step's workgroups fill; value_no_idle_bound: instances / (sum of the "
+                             "in-kernel latencies of the last reference step / CUs), the rate of a device that never waits for a straggler"},
     }
     # K3 on the matrix cores: one [m0 x (nx + N nw)] . [(nx + N nw) x instances-of-the-model] GEMM per model
     rhs_ms = float(np.mean([s["rhs_ms"] for s in stats]))
