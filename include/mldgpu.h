@@ -84,6 +84,11 @@ typedef struct {
                               k_milp_lds (csrc/milp_lds.inc) instead of the dense-dictionary kernel; instances it cannot finish are
                               re-solved by the dense kernel in the same call, bit11 leave those instances at status -1 instead (counting only),
                               bit12 k_milp_lds profile slots = phases inside the simplex (mld_debug_profile). */
+    double time_limit;     /* seconds per INSTANCE on the device clock (Gurobi TimeLimit; the reference passes TimeLimit=20 with every solve,
+                              examples/residential_mg_with_pv_and_dewhs/micro_grid_control_simulation.py:232, forwarded by
+                              controllers/controller_base.py:509-512): the branch-and-bound of an instance ends once it has run that long, like
+                              max_nodes ends it -- status MLD_STATUS_NODE_LIMIT with the incumbent and the proven bound (an instance without an
+                              incumbent still gets its one rescue dive).  0 (default) = no limit. */
 } mld_opts;
 
 /* Linear cost in tiled horizon form (the Python layer parses the reference's string-keyed atoms,
@@ -214,6 +219,26 @@ int mld_problem_set_opts(mld_problem_t *, const mld_opts *opts);
  * disturbance forecast moved on by one step (the first step re-enters at the end of the horizon).  The next
  * mld_solve_resident then solves the NEXT MPC step without any host traffic.  mld_download_inputs reads the current inputs. */
 int mld_advance_batch(mld_problem_t *);
+/* The same with the count of instances that were NOT advanced (n_skipped_out may be NULL).  Equivalence with the reference's plant step:
+ * sim_step_k hands only u_k to lsim_k (controller_base.py:229-239), which re-derives delta_k, z_k (and mu_k) from (x, u, omega) by a feasibility
+ * problem (_compute_aux, mld_model.py:683-686, 701-766); this entry applies the PLANNED (delta_0, z_0) instead.  The two agree when the MLD
+ * model is well posed (x, u, omega determine delta, z), the plan uses no soft-constraint slack in step 0 (or delta, z do not drive the state:
+ * B2 = B3 = 0, as in the example's models) and the simulated model is the controller's model.  Instances that have no usable plan -- status
+ * other than OPTIMAL / NODE_LIMIT, or no incumbent -- keep their state and forecast and are counted; time-varying models
+ * (mld_model_create_tv) and a batch that has not been solved since its upload are refused. */
+int mld_advance_batch2(mld_problem_t *, int32_t *n_skipped_out);
+
+/* MIP start of the resident batch (the reference calls its backend with warm_start=True, controllers/controller_base.py:493,509-512: the
+ * previous values of the variables are the solver's start).  bin_start: batch x n_bin bytes, the values (0 / 1) of the binaries in the order of
+ * the variable layout (step-major, controllers/components/variables.py:189-243); an instance whose first byte is 255 has no start; NULL
+ * clears the start.  The start is used lazily: an instance whose first search passes find no incumbent evaluates it (binaries fixed, one LP)
+ * in place of its dive; a feasible start becomes the incumbent and the search continues around it.  Any upload / selection of new inputs
+ * clears the start. */
+int mld_set_warm_start(mld_problem_t *, const uint8_t *bin_start);
+/* The start built on the device from the last solution of the resident batch: shift = 0 takes the plan as it is (what warm_start=True means
+ * to the reference's backend: the variables' previous values), shift = k > 0 moves it k steps towards the present and repeats its last step
+ * (receding horizon: call after mld_advance_batch).  Instances without an incumbent get no start. */
+int mld_warm_start_from_previous(mld_problem_t *, int shift);
 /* Scenario streaming with everything resident in HBM: the parameter update at the top of the reference's solve() (x_k and
  * omega_tilde set as cvx.Parameter values, controllers/controller_base.py:495-498; the example re-solves with new forecasts every
  * step, micro_grid_control_simulation.py:229-232) for a whole batch.  mld_stage_inputs uploads n_sets input sets of the uploaded

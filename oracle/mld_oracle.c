@@ -44,6 +44,7 @@
 #define ORC_COEF_ZERO 1e-9
 #define ORC_PURGE_SLACK 1e-3
 #define ORC_RESID_TOL 1e-6
+#define ORC_MIR_FMIN 0.005
 #ifndef ORC_PEN_DEFAULT
 #define ORC_PEN_DEFAULT 1
 #endif
@@ -64,6 +65,10 @@ typedef struct {
 typedef struct {
     int nodes, pivots, cuts, refactors, status;
     double root_lp, root_bound, lower_bound;
+    double work;         /* row updates summed over the pivots (rows with a non-zero multiplier): the proxy for the dense kernel's HBM bytes */
+    double bland;        /* pivots taken under Bland's rule (the solve was stalling) */
+    double rebuilds;     /* root rebuilt without cuts (the LP broke down in a cut round) */
+    double phase_work[6];/* work split: root LP, cut rounds (+ MIP start), then the search phases IDS / DIVE / RINS / FINAL */
 } orc_stats;
 
 /* ------------------------------------------------------------------------------------------------
@@ -243,6 +248,8 @@ typedef struct {
     int *basic, *nonbasic, *where; /* where[id] = column index if nonbasic else -1-row */
     unsigned char *at_upper, *is_int, *skip;
     long pivots, max_pivots;
+    double work, bland;
+    int perturbed;        /* the cost row carries the anti-stalling perturbation (dual_simplex_impl) */
     int refactors;
     double *tmp_col, *tmp_row;
     double *dw;           /* dual devex reference weights of the rows (Forrest & Goldfarb 1992), reset at every dual simplex entry */
@@ -390,6 +397,7 @@ static void pivot(dict_t *t, int r, int c, double leave_value)
         if (i == r) continue;
         const double mu = colc[i];
         if (mu == 0.0) continue;
+        t->work += 1.0;
         double *ri = D + (size_t)i * ld;
         for (int k = 0; k <= n; ++k) ri[k] -= mu * rowr[k];
         ri[c] = -mu * inv;
@@ -447,6 +455,7 @@ static double check_residual(const dict_t *t)
 
 static void refactor(dict_t *t)
 {
+    t->perturbed = 0;     /* the dictionary is rebuilt with the true cost row */
     for (int i = 0; i < t->mcap; ++i) t->dw[i] = 1.0;
     const int n = t->n, m = t->m, ld = t->ld;
     t->refactors++;
@@ -505,6 +514,49 @@ static void refactor(dict_t *t)
     free(want); free(rowfree); free(val); free(up);
 }
 
+static void reprice(dict_t *t, const double *cost);
+static int primal_simplex(dict_t *t);
+#define LP_UNBOUNDED 4
+
+/* Anti-stalling cost perturbation (the textbook remedy for dual degeneracy, e.g. Koberstein 2005 section 6.2): when a solve without an
+ * objective cutoff stalls, every non-basic reduced cost is pushed away from zero in its feasible direction by a deterministic pseudo-random
+ * amount of relative size 1e-6..2e-6, which breaks the ties of the dual ratio test.  When the perturbed problem is optimal the true cost row
+ * is restored (reprice) and, if some reduced cost now has the wrong sign, the bounded primal simplex finishes from this primal-feasible basis. */
+#define ORC_PERT 1e-6
+static void perturb_costs(dict_t *t)
+{
+    const int n = t->n;
+    double *d = t->D + (size_t)t->mcap * t->ld;
+    for (int c = 0; c < n; ++c) {
+        const int j = t->nonbasic[c];
+        if (t->lo[j] == t->hi[j]) continue;
+        const unsigned hsh = (unsigned)j * 2654435761u;
+        const double u = (double)(hsh >> 8) * (1.0 / 16777216.0);          /* [0, 1) from the variable's id */
+        const double eps = ORC_PERT * (1.0 + u) * (1.0 + fabs(d[c]));
+        d[c] += t->at_upper[c] ? -eps : eps;
+    }
+    t->perturbed = 1;
+}
+
+/* leaves a perturbed solve: true reduced costs back, primal simplex if they are not dual feasible at an optimum */
+static int unperturb(dict_t *t, int st)
+{
+    if (!t->perturbed) return st;
+    reprice(t, t->q);
+    t->perturbed = 0;
+    if (st != LP_OPTIMAL) return st;
+    const double *d = t->D + (size_t)t->mcap * t->ld;
+    int bad = 0;
+    for (int c = 0; c < t->n && !bad; ++c) {
+        const int j = t->nonbasic[c];
+        if (t->lo[j] == t->hi[j]) continue;
+        if ((t->at_upper[c] ? d[c] : -d[c]) > ORC_DTOL) bad = 1;
+    }
+    if (!bad) return LP_OPTIMAL;
+    const int ps = primal_simplex(t);
+    return ps == LP_OPTIMAL ? LP_OPTIMAL : LP_ITERLIMIT;
+}
+
 static int dual_simplex_impl(dict_t *t, double cutoff)
 {
     const int n = t->n, ld = t->ld;
@@ -512,17 +564,22 @@ static int dual_simplex_impl(dict_t *t, double cutoff)
     for (int i = 0; i < t->mcap; ++i) { t->skip[i] &= 2; t->dw[i] = 1.0; }     /* bit 1 (mark_dead) stays; new devex reference framework: the current basis */
     int stall = 0;
     double last_obj = -INFINITY;
+    static int pert_env = -1;
+    if (pert_env < 0) pert_env = getenv("ORC_NO_PERT") ? 0 : 1;
+    int pert_ok = pert_env && cutoff == INFINITY && !t->P;      /* one perturbation per solve, only where no cutoff reads the (perturbed) objective */
     const double *d = t->D + (size_t)t->mcap * ld;
     long checked_at = t->pivots;     /* pivot count at the last verification against the original rows */
     for (;;) {
-        if (t->pivots >= t->max_pivots) return LP_ITERLIMIT;
+        if (t->pivots >= t->max_pivots) return unperturb(t, LP_ITERLIMIT);
         if (t->pivots - checked_at >= 512) {   /* a long solve never reaches the verification at an optimum: verify on the way */
             checked_at = t->pivots;
             if (check_residual(t) > ORC_RESID_TOL) { refactor(t); for (int i = 0; i < t->mcap; ++i) t->skip[i] &= 2; continue; }
         }
         const double cur = objective(t);
         if (cur > last_obj + 1e-12 * fmax(1.0, fabs(cur))) { stall = 0; last_obj = cur; } else stall++;
+        if (stall > 30 && pert_ok && !t->perturbed) { pert_ok = 0; perturb_costs(t); stall = 0; last_obj = -INFINITY; continue; }
         const int bland = stall > 30;
+        if (getenv("ORC_DEBUG_LP") && t->pivots % 50 == 0) { int nv_ = 0; double sv_ = 0; for (int i = 0; i < m; ++i) { if (t->skip[i]) continue; const int j = t->basic[i]; const double v = fmax(t->lo[j] - t->xB[i], t->xB[i] - t->hi[j]); if (v > ORC_PTOL) { nv_++; sv_ += v; } } fprintf(stderr, "  lp pivots %ld obj %.10f stall %d bland %d infeasible rows %d sum %.3e m %d\n", t->pivots, cur, stall, bland, nv_, sv_, m); }
         /* leaving row: dual devex pricing, largest violation^2 / weight (smallest variable id while stalling) */
         int r = -1; double best_sc = 0.0; int rb = -1; int rb_id = 0x7fffffff;
         for (int i = 0; i < m; ++i) {
@@ -538,7 +595,7 @@ static int dual_simplex_impl(dict_t *t, double cutoff)
         if (r < 0) {
             checked_at = t->pivots;
             if (check_residual(t) > ORC_RESID_TOL) { refactor(t); for (int i = 0; i < t->mcap; ++i) t->skip[i] &= 2; continue; }
-            return LP_OPTIMAL;
+            return unperturb(t, LP_OPTIMAL);
         }
         if (bland) r = rb;
         if (cur >= cutoff) {
@@ -589,7 +646,7 @@ static int dual_simplex_impl(dict_t *t, double cutoff)
                 checked_at = t->pivots;
                 if (check_residual(t) > 0.1 * viol) { refactor(t); for (int i = 0; i < t->mcap; ++i) t->skip[i] &= 2; continue; }
             }
-            return LP_INFEASIBLE;
+            return unperturb(t, LP_INFEASIBLE);
         }
         int cbest = -1; double abest = -1; int idbest = 0x7fffffff;
         for (int c = 0; c < n; ++c) {
@@ -610,13 +667,13 @@ static int dual_simplex_impl(dict_t *t, double cutoff)
              * and with it the bound, is lost (seen: violation 5e-8, pivot 1.7e-7, step 3e9).  The row counts as satisfied. */
             t->skip[r] |= 1; continue;
         }
+        if (bland) t->bland += 1.0;
         pivot(t, r, cbest, below ? t->lo[jr] : t->hi[jr]);
     }
 }
 
 
 /* ---- primal side: re-pricing with a new cost vector, bounded primal simplex, simplicial decomposition ----------- */
-#define LP_UNBOUNDED 4
 #define SD_PMAX 32
 
 /* reduced costs of the current basis for structural cost vector `cost` (slacks cost nothing) */
@@ -679,9 +736,10 @@ static int primal_simplex(dict_t *t)
         /* pass 1: Harris bound */
         double tmax = t->hi[jc] - t->lo[jc];
         double amax = 0;
-        for (int i = 0; i < m; ++i) { const double a = fabs(t->D[(size_t)i * ld + c]); if (a > amax) amax = a; }
+        for (int i = 0; i < m; ++i) { if (t->skip[i] & 2) continue; const double a = fabs(t->D[(size_t)i * ld + c]); if (a > amax) amax = a; }
         const double ptol = fmax(ORC_PIV_ABS, ORC_PIV_REL * amax);
         for (int i = 0; i < m; ++i) {
+            if (t->skip[i] & 2) continue;      /* rows that cannot bind / dropped cut rows are not maintained (linear-cost mode only) */
             const double a = t->D[(size_t)i * ld + c] * dir;
             if (fabs(a) <= ptol) continue;
             const int j = t->basic[i];
@@ -692,6 +750,7 @@ static int primal_simplex(dict_t *t)
         /* pass 2: largest pivot among rows whose exact ratio is within the bound */
         int r = -1; double abest = -1;
         for (int i = 0; i < m; ++i) {
+            if (t->skip[i] & 2) continue;
             const double a = t->D[(size_t)i * ld + c] * dir;
             if (fabs(a) <= ptol) continue;
             const int j = t->basic[i];
@@ -705,7 +764,7 @@ static int primal_simplex(dict_t *t)
             /* bound flip */
             const double nw = t->at_upper[c] ? t->lo[jc] : t->hi[jc];
             const double dl = nw - t->xN[c];
-            for (int i = 0; i < m; ++i) t->xB[i] -= t->D[(size_t)i * ld + c] * dl;
+            for (int i = 0; i < m; ++i) if (!(t->skip[i] & 2)) t->xB[i] -= t->D[(size_t)i * ld + c] * dl;
             t->xN[c] = nw; t->at_upper[c] = !t->at_upper[c];
             t->pivots++;
             continue;
@@ -1015,7 +1074,10 @@ static double mir_build(const dict_t *t, int i, double delta, const double *x, d
         }
     }
     const double b = rhs / delta, fb = floor(b), f = b - fb;
-    if (f < 0.05 || f > 0.95) return -1.0;
+    /* the fractional part must lie in [ORC_MIR_FMIN, 1 - ORC_MIR_FMIN] (round 3: 0.005, was 0.05 -- the strongest roundings of the tank rows are the
+     * "just barely needs one more heating step" ones, f ~ 0.003 .. 0.03; csrc/problem.inc S_MIR_FMIN) */
+    { static double fmin_ = -1.0; if (fmin_ < 0) fmin_ = getenv("ORC_MIR_FMIN") ? atof(getenv("ORC_MIR_FMIN")) : ORC_MIR_FMIN;
+      if (f < fmin_ || f > 1.0 - fmin_) return -1.0; }
     double lhs = 0.0, nrm2 = 0.0, bx = fb;
     const double kc = 1.0 / (delta * (1.0 - f));
     for (int j = 0; j < n; ++j) {
@@ -1124,23 +1186,99 @@ static void penalties(const dict_t *t, int r, double *pd_out, double *pu_out)
     *pu_out = isfinite(ru) ? ru * (1.0 - f) : INFINITY;
 }
 
+/* Evaluation of a complete binary assignment (a leaf of the search, or a MIP start): every free binary is fixed at the rounded entry of
+ * vals[], the remaining LP (QP) is solved on the same dictionary, the point is verified against the ORIGINAL rows and kept as the incumbent
+ * when it is feasible and better; the bounds are restored.  Returns 1 when the rounded point is feasible. */
+typedef struct {
+    int n, m, nb; const int *bins;
+    const double *Pq, *q, *G, *h, *lb, *ub;
+    int *sv_j; double *sv_lo, *sv_hi, *xo;
+    double *best; int *have; double *x_out; int *unbounded;
+} leaf_ctx;
+
+static int leaf_eval(dict_t *t, leaf_ctx *L, const double *vals)
+{
+    const int n = L->n, m = L->m, nb = L->nb; const int *bins = L->bins;
+    double *xo = L->xo;
+    int ns = 0;
+    for (int k = 0; k < nb; ++k) {
+        const int j = bins[k];
+        if (t->lo[j] != t->hi[j]) { L->sv_j[ns] = j; L->sv_lo[ns] = t->lo[j]; L->sv_hi[ns] = t->hi[j]; ns++; const double v = fmin(fmax(rint(vals[j]), t->lo[j]), t->hi[j]); set_bounds(t, j, v, v); }
+    }
+    int leaf_ok = dual_simplex(t, INFINITY) == LP_OPTIMAL;
+    if (leaf_ok && t->P) { double lbq, fvq; leaf_ok = sd_relax(t, INFINITY, &lbq, &fvq) == 0; }
+    if (leaf_ok) {
+        if (t->P) for (int j = 0; j < n; ++j) xo[j] = t->vcur[j] * t->cs[j];
+        else {
+            for (int c = 0; c < n; ++c) if (t->nonbasic[c] < n) xo[t->nonbasic[c]] = t->xN[c] * t->cs[t->nonbasic[c]];
+            for (int r = 0; r < t->m; ++r) if (t->basic[r] < n) xo[t->basic[r]] = t->xB[r] * t->cs[t->basic[r]];
+        }
+        for (int k = 0; k < nb; ++k) xo[bins[k]] = rint(xo[bins[k]]);
+        double ob = 0; for (int j = 0; j < n; ++j) ob += L->q[j] * xo[j];
+        if (L->Pq) for (int i = 0; i < n; ++i) { const double *pi = L->Pq + (size_t)i * n; double sq = 0; for (int j = 0; j < n; ++j) sq += pi[j] * xo[j]; ob += 0.5 * xo[i] * sq; }
+        int feas = 1;
+        for (int i = 0; i < m && feas; ++i) {
+            double sa = -L->h[i]; const double *gi = L->G + (size_t)i * n;
+            for (int j = 0; j < n; ++j) sa += gi[j] * xo[j];
+            if (sa * t->rs[i] > 1e-6) feas = 0;
+        }
+        if (feas && ob < *L->best) { *L->best = ob; *L->have = 1; memcpy(L->x_out, xo, sizeof(double) * n); }
+        if (feas && t->P)   /* (QP relaxations: a free variable resting on the artificial box counts as no finite optimum) */
+            for (int j = 0; j < n; ++j)
+                if ((L->lb[j] == -INFINITY && xo[j] / t->cs[j] <= -0.999 * ORC_BIG) || (L->ub[j] == INFINITY && xo[j] / t->cs[j] >= 0.999 * ORC_BIG)) *L->unbounded = 1;
+        if (feas && !t->P) {
+            /* A free variable resting NON-BASIC on the artificial box (+-ORC_BIG) with a non-zero reduced cost: the value
+             * still falls along its ray -- no finite optimum.  With a zero reduced cost the box is only where a
+             * variable the objective does not depend on happens to sit: the optimum is finite (found by the fuzz
+             * test: a zero-cost auxiliary z whose column only relaxes the rows; round 1 called that unbounded). */
+            const double *dd = t->D + (size_t)t->mcap * t->ld;
+            for (int c = 0; c < n; ++c) {
+                const int j = t->nonbasic[c];
+                if (j >= n || fabs(dd[c]) <= 1e-9) continue;
+                if ((L->lb[j] == -INFINITY && t->xN[c] <= -0.999 * ORC_BIG) || (L->ub[j] == INFINITY && t->xN[c] >= 0.999 * ORC_BIG)) *L->unbounded = 1;
+            }
+        }
+        leaf_ok = feas;
+    }
+    for (int k = 0; k < ns; ++k) set_bounds(t, L->sv_j[k], L->sv_lo[k], L->sv_hi[k]);
+    return leaf_ok;
+}
+
 static double gtol(const orc_opts *o, double v) { return fmax(o->gap_abs, o->gap_rel * fabs(v)); }
+
+static int solve_core(int n, int m, const double *Pq, const double *q, const double *G, const double *h, const double *lb_in,
+                      const double *ub_in, const unsigned char *is_bin, const orc_opts *o, const double *x_start, double *x_out,
+                      double *obj_out, orc_stats *st);
 
 int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double *G, const double *h, const double *lb_in,
                    const double *ub_in, const unsigned char *is_bin, const orc_opts *o, double *x_out,
-                   double *obj_out, orc_stats *st);
+                   double *obj_out, orc_stats *st)
+{
+    return solve_core(n, m, Pq, q, G, h, lb_in, ub_in, is_bin, o, NULL, x_out, obj_out, st);
+}
 
 int orc_solve_milp(int n, int m, const double *q, const double *G, const double *h, const double *lb_in,
                    const double *ub_in, const unsigned char *is_bin, const orc_opts *o, double *x_out,
                    double *obj_out, orc_stats *st)
 {
-    return orc_solve_miqp(n, m, NULL, q, G, h, lb_in, ub_in, is_bin, o, x_out, obj_out, st);
+    return solve_core(n, m, NULL, q, G, h, lb_in, ub_in, is_bin, o, NULL, x_out, obj_out, st);
+}
+
+/* MIP start (the reference forwards warm_start=True to its backend, controllers/controller_base.py:493,509-512: the previous values of the
+ * variables are the solver's start).  x_start (n values, NULL = none): its binaries, rounded, are fixed after the root LP, the remaining LP is
+ * solved and, when the point satisfies the original rows, it is the initial incumbent: its value is the cutoff of everything that follows and the
+ * cut loop stops as soon as the bound is within the gap of it. */
+int orc_solve_miqp_start(int n, int m, const double *Pq, const double *q, const double *G, const double *h, const double *lb_in,
+                         const double *ub_in, const unsigned char *is_bin, const orc_opts *o, const double *x_start, double *x_out,
+                         double *obj_out, orc_stats *st)
+{
+    return solve_core(n, m, Pq, q, G, h, lb_in, ub_in, is_bin, o, x_start, x_out, obj_out, st);
 }
 
 /* min 1/2 x'Px + q'x  s.t. Gx <= h, lb <= x <= ub, x_i in {0,1} (i binary);  P symmetric PSD or NULL */
-int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double *G, const double *h, const double *lb_in,
-                   const double *ub_in, const unsigned char *is_bin, const orc_opts *o, double *x_out,
-                   double *obj_out, orc_stats *st)
+static int solve_core(int n, int m, const double *Pq, const double *q, const double *G, const double *h, const double *lb_in,
+                      const double *ub_in, const unsigned char *is_bin, const orc_opts *o, const double *x_start, double *x_out,
+                      double *obj_out, orc_stats *st)
 {
     memset(st, 0, sizeof(*st));
     st->root_lp = st->root_bound = NAN; st->lower_bound = -INFINITY;
@@ -1202,12 +1340,14 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
     double *stk_first = dalloc(nb + 2);
     unsigned char *stk_second = (unsigned char *)calloc(nb + 2, 1);
     int *sv_j = (int *)calloc(nb + 2, sizeof(int)); double *sv_lo = dalloc(nb + 2), *sv_hi = dalloc(nb + 2);
-    int lp = LP_OPTIMAL, root_ok = 0;
+    int lp = LP_OPTIMAL, root_ok = 0, unbounded = 0, started = 0;
+    leaf_ctx L = { n, m, nb, bins, Pq, q, G, h, lb, ub, sv_j, sv_lo, sv_hi, xo, &best, &have, x_out, &unbounded };
     st->nodes = 1;
     /* root LP + cut rounds; if the LP breaks down while cutting the root is rebuilt and solved without cuts */
     for (int attempt = 0; attempt < 2 && !root_ok; ++attempt) {
         const int use_cuts = attempt == 0 && o->cut_rounds > 0;
         if (attempt) {
+            st->rebuilds += 1.0;
             t->m = m;
             reset_dictionary(t);
             for (int c = 0; c < n; ++c) place(t, c);
@@ -1216,15 +1356,27 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
         lp = dual_simplex(t, INFINITY);
         if (lp != LP_OPTIMAL) { status = lp == LP_INFEASIBLE ? ORC_INFEASIBLE : ORC_NUMERICAL; goto done; }
         if (!attempt) st->root_lp = objective(t);
+        st->phase_work[0] = t->work;
         root_ok = 1;
         st->cuts = 0;
+        if (x_start && !started && getenv("ORC_WARM_EAGER")) {
+            /* (study variant: the start evaluated before the cut loop)  MIP start: the start's binaries as a leaf -- the initial incumbent when it satisfies the original rows -- then back to the root optimum */
+            started = 1;
+            leaf_eval(t, &L, x_start);
+            st->nodes++;
+            lp = dual_simplex(t, INFINITY);
+            if (lp != LP_OPTIMAL) { root_ok = 0; continue; }
+        }
         if (use_cuts) {
             int stalled = 0;
             const long saved_cap = t->max_pivots;
             for (int rnd = 0; rnd < o->cut_rounds; ++rnd) {
                 const double before = objective(t);
+                if (have && best - gtol(o, best) <= before) break;      /* the incumbent is within the gap of the bound: no more cuts needed */
                 int k = gmi_round(t, o->cuts_per_round);
+                const int kg = k;
                 if (o->mir_per_round > 0) k += mir_round(t, o->mir_per_round);
+                if (getenv("ORC_DEBUG_CUTS")) fprintf(stderr, "cut round %d: obj %.6f gmi %d mir %d rows %d\n", rnd, before, kg, k - kg, t->m);
                 if (!k) break;
                 st->cuts += k;
                 const long cap = t->pivots + 4L * m + 200;
@@ -1239,6 +1391,7 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
             if (root_ok && !t->P) for (int i = m; i < t->m; ++i) if (t->basic[i] == n + i && t->xB[i] > ORC_PURGE_SLACK) t->skip[i] |= 2;
         }
     }
+    st->phase_work[1] = t->work - st->phase_work[0];
     if (!root_ok) { status = ORC_NUMERICAL; goto done; }
     if (t->P) {   /* root bound of the QP relaxation */
         double lbq, fvq;
@@ -1246,6 +1399,15 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
         st->root_bound = lbq;
     } else
     st->root_bound = objective(t);
+    if (getenv("ORC_DUMP_ROOT")) {   /* study only: the root point after cuts (unscaled), one value per line */
+        FILE *fp = fopen(getenv("ORC_DUMP_ROOT"), "w");
+        if (fp) {
+            for (int c = 0; c < n; ++c) if (t->nonbasic[c] < n) xs[t->nonbasic[c]] = t->xN[c];
+            for (int r = 0; r < t->m; ++r) if (t->basic[r] < n) xs[t->basic[r]] = t->xB[r];
+            for (int j = 0; j < n; ++j) fprintf(fp, "%.17g\n", xs[j] * t->cs[j]);
+            fclose(fp);
+        }
+    }
     memcpy(root_lo, t->lo, sizeof(double) * n); memcpy(root_hi, t->hi, sizeof(double) * n);
     {
         /* Depth-first branch-and-bound with iterative deepening on the LP bound (Korf 1985): pass k
@@ -1262,16 +1424,18 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
         enum { PH_IDS = 0, PH_DIVE, PH_RINS, PH_FINAL };
         const double root_bound = st->root_bound;
         int nodes = 0, limit = 0, pass = 0, rescue = 0, node_budget = o->max_nodes;
-        int phase = PH_IDS, rins_rounds = 0, nfix = 0, unbounded = 0;
-        const int ids_cap = o->max_nodes / 8 > 16 ? o->max_nodes / 8 : 16;
+        int phase = started && have ? PH_FINAL : PH_IDS, rins_rounds = 0, nfix = 0;     /* with a MIP start: guided search towards it from the first node */
+        int ids_cap = o->max_nodes / 8 > 16 ? o->max_nodes / 8 : 16;
+        if (getenv("ORC_IDS_CAP")) { const int c = atoi(getenv("ORC_IDS_CAP")); if (c < ids_cap) ids_cap = c; }
         const double dive_tol = 1e-2 * fmax(1.0, fabs(root_bound));
         double *xroot = dalloc(nb + 1), *fx_lo = dalloc(nb + 1), *fx_hi = dalloc(nb + 1);
         int *fx_j = (int *)calloc(nb + 1, sizeof(int));
-        double T = root_bound + fmax(1e-7 * fmax(1.0, fabs(root_bound)), gtol(o, root_bound));
+        double T = have ? INFINITY : root_bound + fmax(1e-7 * fmax(1.0, fabs(root_bound)), gtol(o, root_bound));
         const int pen_mode = getenv("ORC_PEN") ? atoi(getenv("ORC_PEN")) : ORC_PEN_DEFAULT;   /* 0: first fractional binary in index order (A/B) */
         double lbg = root_bound;      /* proven global lower bound: raised by every exhaustive pass */
         status = ORC_NODE_LIMIT;
         for (;;) {
+            const double work_at_pass = t->work; const int phase_at_pass = phase;
             int depth = 0;
             double t_next = INFINITY;   /* smallest bound among nodes pruned by T only */
             int finished = 0, dive_end = 0;
@@ -1375,47 +1539,7 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                         }
                         if (branch_j < 0 && !pruned) {
                             /* leaf: fix every binary at its rounded value, re-solve, verify, restore */
-                            int ns = 0;
-                            for (int k = 0; k < nb; ++k) {
-                                const int j = bins[k];
-                                if (t->lo[j] != t->hi[j]) { sv_j[ns] = j; sv_lo[ns] = t->lo[j]; sv_hi[ns] = t->hi[j]; ns++; const double v = rint(xs[j]); set_bounds(t, j, v, v); }
-                            }
-                            int leaf_ok = dual_simplex(t, INFINITY) == LP_OPTIMAL;
-                            if (leaf_ok && t->P) { double lbq, fvq; leaf_ok = sd_relax(t, INFINITY, &lbq, &fvq) == 0; }
-                            if (leaf_ok) {
-                                if (t->P) for (int j = 0; j < n; ++j) xo[j] = t->vcur[j] * t->cs[j];
-                                else {
-                                for (int c = 0; c < n; ++c) if (t->nonbasic[c] < n) xo[t->nonbasic[c]] = t->xN[c] * t->cs[t->nonbasic[c]];
-                                for (int r = 0; r < t->m; ++r) if (t->basic[r] < n) xo[t->basic[r]] = t->xB[r] * t->cs[t->basic[r]];
-                                }
-                                for (int k = 0; k < nb; ++k) xo[bins[k]] = rint(xo[bins[k]]);
-                                double ob = 0; for (int j = 0; j < n; ++j) ob += q[j] * xo[j];
-                                if (Pq) for (int i = 0; i < n; ++i) { const double *pi = Pq + (size_t)i * n; double sq = 0; for (int j = 0; j < n; ++j) sq += pi[j] * xo[j]; ob += 0.5 * xo[i] * sq; }
-                                int feas = 1;
-                                for (int i = 0; i < m && feas; ++i) {
-                                    double sa = -h[i]; const double *gi = G + (size_t)i * n;
-                                    for (int j = 0; j < n; ++j) sa += gi[j] * xo[j];
-                                    if (sa * t->rs[i] > 1e-6) feas = 0;
-                                }
-                                if (feas && ob < best) { best = ob; have = 1; memcpy(x_out, xo, sizeof(double) * n); }
-                                if (feas && t->P)   /* (QP relaxations: a free variable resting on the artificial box counts as no finite optimum) */
-                                    for (int j = 0; j < n; ++j)
-                                        if ((lb[j] == -INFINITY && xo[j] / t->cs[j] <= -0.999 * ORC_BIG) || (ub[j] == INFINITY && xo[j] / t->cs[j] >= 0.999 * ORC_BIG)) unbounded = 1;
-                                if (feas && !t->P) {
-                                    /* A free variable resting NON-BASIC on the artificial box (+-ORC_BIG) with a non-zero reduced cost: the value
-                                     * still falls along its ray -- no finite optimum.  With a zero reduced cost the box is only where a
-                                     * variable the objective does not depend on happens to sit: the optimum is finite (found by the fuzz
-                                     * test: a zero-cost auxiliary z whose column only relaxes the rows; round 1 called that unbounded). */
-                                    const double *dd = t->D + (size_t)t->mcap * t->ld;
-                                    for (int c = 0; c < n; ++c) {
-                                        const int j = t->nonbasic[c];
-                                        if (j >= n || fabs(dd[c]) <= 1e-9) continue;
-                                        if ((lb[j] == -INFINITY && t->xN[c] <= -0.999 * ORC_BIG) || (ub[j] == INFINITY && t->xN[c] >= 0.999 * ORC_BIG)) unbounded = 1;
-                                    }
-                                }
-                                leaf_ok = feas;
-                            }
-                            for (int k = 0; k < ns; ++k) set_bounds(t, sv_j[k], sv_lo[k], sv_hi[k]);
+                            int leaf_ok = leaf_eval(t, &L, xs);
                             if (!leaf_ok) {
                                 /* The rounded point is not feasible although every binary is within the integrality
                                  * tolerance: with big-M rows a binary at 1e-6 can carry a whole unit of the row.  The
@@ -1470,12 +1594,21 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
                 stk_second[depth - 1] = 1;
                 { const int j = stk_j[depth - 1]; const double v = 1.0 - stk_first[depth - 1]; set_bounds(t, j, v, v); }
             }
+            st->phase_work[2 + phase_at_pass] += t->work - work_at_pass;
             if (phase == PH_RINS) {   /* release the fixings */
                 for (int k = 0; k < nfix; ++k) { const int j = fx_j[k]; root_lo[j] = fx_lo[k]; root_hi[j] = fx_hi[k]; set_bounds(t, j, fx_lo[k], fx_hi[k]); }
                 rins_rounds++;
             }
             if (finished) { if (unbounded) { status = ORC_UNBOUNDED; best = -INFINITY; } else if (!rescue) status = ORC_OPTIMAL; break; }
             if (lp == LP_ITERLIMIT) break;
+            if (phase == PH_IDS && limit && !have && !rescue && nodes < o->max_nodes && x_start && !started) {
+                /* MIP start, evaluated lazily: only an instance whose deepening passes found no incumbent pays for it (one leaf); a feasible
+                 * start then takes the place of the dive and the search continues with RINS around it */
+                started = 1;
+                nodes++;
+                leaf_eval(t, &L, x_start);
+                if (have) { phase = PH_RINS; limit = 0; T = INFINITY; node_budget = nodes + o->max_nodes / 4 < o->max_nodes ? nodes + o->max_nodes / 4 : o->max_nodes; continue; }
+            }
             if (phase == PH_IDS && limit && !have && !rescue && nodes < o->max_nodes) {
                 /* the dive may finish even when it outlasts the node budget (it is what guarantees a feasible point) */
                 phase = PH_DIVE; limit = 0; T = INFINITY;
@@ -1519,7 +1652,7 @@ int orc_solve_miqp(int n, int m, const double *Pq, const double *q, const double
     }
 done:
     if (Ps) { free(Ps); free(t->Y); free(t->PY); free(t->Hm); free(t->cm); free(t->wm); free(t->gcost); free(t->vcur); free(t->Pv); }
-    st->pivots = (int)t->pivots; st->refactors = t->refactors; st->status = status;
+    st->pivots = (int)t->pivots; st->refactors = t->refactors; st->status = status; st->work = t->work; st->bland = t->bland;
     *obj_out = have ? best : INFINITY;
     free(lb); free(ub); free(t->D); free(t->Gx); free(t->hx); free(t->q); free(t->rs); free(t->cs); free(t->lo);
     free(t->hi); free(t->xB); free(t->xN); free(t->basic); free(t->nonbasic); free(t->where); free(t->at_upper);

@@ -29,7 +29,7 @@ class Opts(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("nodes", C.c_int), ("pivots", C.c_int), ("cuts", C.c_int), ("refactors", C.c_int),
                 ("status", C.c_int), ("root_lp", C.c_double), ("root_bound", C.c_double),
-                ("lower_bound", C.c_double)]
+                ("lower_bound", C.c_double), ("work", C.c_double), ("bland", C.c_double), ("rebuilds", C.c_double), ("phase_work", C.c_double * 6)]
 
 
 def build(force=False):
@@ -61,7 +61,10 @@ def make_opts(gap_abs=1e-9, gap_rel=0.0, max_nodes=100000, cut_rounds=10, cuts_p
     return Opts(gap_abs, gap_rel, max_nodes, cut_rounds, cuts_per_round, max_cuts, max_pivots, presolve, mir_per_round)
 
 
-def solve_milp(q, G, h, lb, ub, is_bin, **kw):
+def solve_milp(q, G, h, lb, ub, is_bin, x_start=None, **kw):
+    """x_start: MIP start (n values; its binaries, rounded, become the initial incumbent when feasible) -- orc_solve_miqp_start"""
+    if x_start is not None:
+        return _solve_start(None, q, G, h, lb, ub, is_bin, x_start, **kw)
     q = np.ascontiguousarray(q, np.float64)
     G = np.ascontiguousarray(G, np.float64)
     h = np.ascontiguousarray(h, np.float64)
@@ -77,7 +80,29 @@ def solve_milp(q, G, h, lb, ub, is_bin, **kw):
                              C.byref(o), _p(x), C.byref(obj), C.byref(st))
     return dict(status=STATUS[s], obj=obj.value, x=x if (np.isfinite(obj.value) or s == 4) else None, nodes=st.nodes,
                 pivots=st.pivots, cuts=st.cuts, refactors=st.refactors, root_lp=st.root_lp,
-                root_bound=st.root_bound, lower_bound=st.lower_bound)
+                root_bound=st.root_bound, lower_bound=st.lower_bound, work=st.work, bland=st.bland, rebuilds=st.rebuilds, phase_work=list(st.phase_work))
+
+
+def _solve_start(P, q, G, h, lb, ub, is_bin, x_start, **kw):
+    q = np.ascontiguousarray(q, np.float64)
+    G = np.ascontiguousarray(G, np.float64)
+    h = np.ascontiguousarray(h, np.float64)
+    lb = np.ascontiguousarray(lb, np.float64)
+    ub = np.ascontiguousarray(ub, np.float64)
+    ib = np.ascontiguousarray(is_bin, np.uint8)
+    xs = np.ascontiguousarray(x_start, np.float64)
+    Pc = np.ascontiguousarray(P, np.float64) if P is not None else None
+    m, n = G.shape
+    x = np.zeros(n)
+    obj = C.c_double()
+    st = Stats()
+    o = make_opts(**kw)
+    lib().orc_solve_miqp_start.restype = C.c_int
+    s = lib().orc_solve_miqp_start(n, m, _p(Pc), _p(q), _p(G), _p(h), _p(lb), _p(ub), ib.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                   C.byref(o), _p(xs), _p(x), C.byref(obj), C.byref(st))
+    return dict(status=STATUS[s], obj=obj.value, x=x if (np.isfinite(obj.value) or s == 4) else None, nodes=st.nodes,
+                pivots=st.pivots, cuts=st.cuts, refactors=st.refactors, root_lp=st.root_lp,
+                root_bound=st.root_bound, lower_bound=st.lower_bound, work=st.work, bland=st.bland, rebuilds=st.rebuilds, phase_work=list(st.phase_work))
 
 
 def solve_milp_batch(qs, Gs, hs, lb, ub, is_bin, threads=0, **kw):

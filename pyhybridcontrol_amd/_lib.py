@@ -32,7 +32,7 @@ class Opts(C.Structure):
     _fields_ = [("gap_abs", C.c_double), ("gap_rel", C.c_double), ("max_nodes", C.c_int32),
                 ("max_pivots", C.c_int32), ("cut_rounds", C.c_int32), ("cuts_per_round", C.c_int32),
                 ("max_cuts", C.c_int32), ("presolve", C.c_int32), ("n_slots", C.c_int32), ("mir_per_round", C.c_int32),
-                ("flags", C.c_int32), ("reserved", C.c_int32)]
+                ("flags", C.c_int32), ("reserved", C.c_int32), ("time_limit", C.c_double)]
 
 
 class Cost(C.Structure):
@@ -52,7 +52,7 @@ EXPORTS = ("mld_device_count", "mld_set_device", "mld_last_error", "mld_version"
            "mld_model_create", "mld_model_create_tv", "mld_model_destroy", "mld_condense_device", "mld_condense", "mld_condense_device_f32", "mld_condense_f32", "mld_opts_default",
            "mld_problem_create", "mld_problem_set_cost", "mld_problem_destroy", "mld_cost_assemble",
            "mld_solve_batch", "mld_upload_batch", "mld_upload_constraint_blocks", "mld_solve_resident", "mld_problem_use_stream", "mld_solve_launch", "mld_solve_finish", "mld_download_results", "mld_download_telemetry",
-           "mld_rhs_batch", "mld_problem_set_opts", "mld_advance_batch", "mld_download_inputs", "mld_stage_inputs", "mld_select_inputs", "mld_gather_results",
+           "mld_rhs_batch", "mld_problem_set_opts", "mld_advance_batch", "mld_advance_batch2", "mld_set_warm_start", "mld_warm_start_from_previous", "mld_download_inputs", "mld_stage_inputs", "mld_select_inputs", "mld_gather_results",
            "mld_comm_unique_id", "mld_comm_init", "mld_gather", "mld_comm_destroy")
 
 

@@ -112,7 +112,7 @@ class GpuModel(object):
 def make_opts(**kw):
     o = _lib.Opts()
     check(_lib.load().mld_opts_default(C.byref(o)))
-    alias = dict(MIPGap="gap_rel", NodeLimit="max_nodes", IterationLimit="max_pivots")
+    alias = dict(MIPGap="gap_rel", NodeLimit="max_nodes", IterationLimit="max_pivots", TimeLimit="time_limit")
     for k, v in kw.items():
         k = alias.get(k, k)
         if not hasattr(o, k):
@@ -220,18 +220,40 @@ class GpuProblem(object):
     def set_opts(self, **opts):
         """limits / tolerances of the existing problem (mld_problem_set_opts): MIPGap, NodeLimit, IterationLimit, gap_abs, cut
         rounds, reserved -- no rebuild, like the per-call solver kwargs of the reference's solve()"""
-        alias = dict(MIPGap="gap_rel", NodeLimit="max_nodes", IterationLimit="max_pivots")
+        alias = dict(MIPGap="gap_rel", NodeLimit="max_nodes", IterationLimit="max_pivots", TimeLimit="time_limit")
         for k, v in opts.items():
             k = alias.get(k, k)
             if k in ("max_cuts", "n_slots", "presolve") or not hasattr(self.opts, k):
                 raise TypeError("option %r cannot be changed on an existing problem" % k)
+            if k == "flags" and int(v) != int(self.opts.flags):
+                raise TypeError("flags (MLD_F32) are fixed when the problem is created")
             setattr(self.opts, k, type(getattr(self.opts, k))(v))
         check(_lib.load().mld_problem_set_opts(self._h, C.byref(self.opts)))
 
     def advance(self):
-        """receding horizon on device (mld_advance_batch): x0 <- plant update with the step-0 slice of the last solution,
-        disturbance forecast moved on by one step; the next solve_resident() is the next MPC step"""
-        check(_lib.load().mld_advance_batch(self._h))
+        """receding horizon on device (mld_advance_batch2): x0 <- plant update with the step-0 slice of the last solution,
+        disturbance forecast moved on by one step; the next solve_resident() is the next MPC step.  Returns the number of
+        instances that were NOT advanced because their solve left no usable plan (they keep state and forecast)."""
+        skipped = C.c_int32(0)
+        check(_lib.load().mld_advance_batch2(self._h, C.byref(skipped)))
+        return int(skipped.value)
+
+    def set_warm_start(self, bin_start):
+        """MIP start of the resident batch (mld_set_warm_start): (batch, n_bin) values of the binaries, a row starting with 255 = no
+        start for that instance; None clears.  A full decision vector (batch, n) is accepted too (its binaries are rounded)."""
+        if bin_start is None:
+            check(_lib.load().mld_set_warm_start(self._h, None))
+            return
+        a = np.asarray(bin_start)
+        if a.ndim >= 1 and a.reshape(self.batch, -1).shape[1] == self.n and self.n != self.n_bin:
+            a = np.rint(a.reshape(self.batch, self.n)[:, self.is_bin])
+        a = np.ascontiguousarray(a.reshape(self.batch, self.n_bin), dtype=np.uint8)
+        check(_lib.load().mld_set_warm_start(self._h, a.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def warm_start_from_previous(self, shift=0):
+        """MIP start from the last solution, on device (mld_warm_start_from_previous): shift 0 = the plan as it is (warm_start=True of
+        the reference's backend), shift k = moved k steps on with the last step repeated (after advance())"""
+        check(_lib.load().mld_warm_start_from_previous(self._h, int(shift)))
 
     def stage(self, x0_sets, omega_sets):
         """input sets of the uploaded batch's size resident in HBM (mld_stage_inputs): x0_sets (n_sets, batch, nx), omega_sets
