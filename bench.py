@@ -49,7 +49,8 @@ def parse():
     ap.add_argument("--pivot-limit", type=int, default=40000, help="per-instance simplex iteration limit")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="instances timed with the CPU oracle on all cores (0 = skip)")
     ap.add_argument("--exact-sample", type=int, default=-1, help="instances of the exact-gap leg (-1 = the whole shard, 0 = skip)")
-    ap.add_argument("--closed-loop-steps", type=int, default=6, help="steps of the closed-loop leg after the timed region (0 = skip)")
+    ap.add_argument("--closed-loop-steps", type=int, default=24, help="steps of the closed-loop leg after the timed region (0 = skip)")
+    ap.add_argument("--closed-loop-cold", action="store_true", help="closed-loop leg without the MIP start from the shifted previous plan")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--handles", type=int, default=2, help="problem handles (each with its own HIP stream and workspace) the timed steps alternate over: "
                     "the workgroups of step k+1 move onto the CUs the stragglers of step k leave idle; 1 = one step after another")
@@ -82,6 +83,15 @@ def make_shard(n_agents, n_scen, scen_offset):
     # flatten i = s * n_agents + a  
     midx = np.tile(np.arange(n_agents, dtype=np.int32), n_scen)
     return agents, N_p, N_t, x0.reshape(-1, nx), om.reshape(-1, nW), midx
+
+
+def step_scenarios(rank, t, n_local):
+    """scenario set t >= 1 of a rank's timed region: (x0, omega) of its n_local instances, instance i on agent i % n_agents like set 0.
+    Seeded by (cfg4 seed, 7919, rank, t) -- tests/golden/solve_cfg4_timed.npz pins the first instances of (rank 0, t = 1)."""
+    from pyhybridcontrol_amd import synthetic as syn
+    cfg = syn.CONFIGS["cfg4"]
+    rng = np.random.Generator(np.random.PCG64([cfg["seed"], 7919, rank, t]))
+    return syn.make_scenarios(cfg["n_h"], cfg["N_p"] + 1, n_local, rng)
 
 
 def host_description():
@@ -140,29 +150,49 @@ def cpu_baseline(agents, N_p, N_t, x0, om, midx, n_sample, gap, node_limit, pivo
                sample="%d instances spread over the rank-0 shard (all %d agents, scenarios 0..%d), same MIPGap/NodeLimit/IterationLimit, "
                       "oracle/mld_oracle.c with OpenMP over instances on %d threads (%d proven, %d node-limited); value_1t: the first %d of them on one thread"
                       % (len(idx), len(forms), x0.shape[0] // len(agents) - 1, used, int((ra["status"] == 0).sum()), int((ra["status"] == 2).sum()), n1))
-    # an independent third-party CPU solver on the same instances (original, un-tightened rows), if scipy is there
+    # an independent third-party CPU solver on the SAME sample (original, un-tightened rows): scipy's HiGHS at the same MIPGap, one process per
+    # core (the instances are independent -- SURVEY 8d "as an independent third-party CPU reference"), and the one-thread rate beside it
     try:
-        from scipy.optimize import milp, LinearConstraint, Bounds
-        t_h, n_h = 0.0, 0
-        for i in idx[:8]:
+        import multiprocessing as mp
+        for i in idx:
             a = int(midx[i])
-            ag = agents[a]
             if a not in raw:
-                raw[a] = cn.standard_form(ag["mats"], ag["atoms"], N_p, N_t, nu_l=ag["dims"]["nu_l"])
-            sf = raw[a]
-            h = cn.rhs(sf["evo"], x0[i], om[i])
-            q = cn.lin_cost(sf["cost"], x0[i], om[i])
-            t0 = time.perf_counter()
-            milp(q, constraints=LinearConstraint(sf["G"], -np.inf, h), bounds=Bounds(sf["lb"], sf["ub"]),
-                 integrality=sf["is_bin"].astype(int), options=dict(mip_rel_gap=gap))
-            t_h += time.perf_counter() - t0
-            n_h += 1
-        out["third_party"] = dict(solver="scipy.optimize.milp (HiGHS), mip_rel_gap=%g, 1 thread" % gap,
-                                  value=round(n_h / t_h, 3), unit="agent-solves/s", sample="first %d instances of the sample" % n_h)
+                raw[a] = cn.standard_form(agents[a]["mats"], agents[a]["atoms"], N_p, N_t, nu_l=agents[a]["dims"]["nu_l"])
+        _HIGHS.update(raw=raw, x0=x0, om=om, midx=midx, gap=gap)
+        t0 = time.perf_counter()
+        one = [_highs_one(int(i)) for i in idx[:8]]
+        t_1 = time.perf_counter() - t0
+        procs = max(1, min(host["usable_cores"], len(idx)))
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(procs) as pool:       # fork, never spawn / exec: nothing in this process has touched the GPU yet (main() runs this leg first)
+            res = pool.map(_highs_one, [int(i) for i in idx], chunksize=max(1, len(idx) // (4 * procs)))
+        t_all = time.perf_counter() - t0
+        out["third_party"] = dict(solver="scipy.optimize.milp (HiGHS), mip_rel_gap=%g, original rows" % gap, value_all=round(len(idx) / t_all, 3),
+                                  cores=procs, value=round(len(one) / t_1, 3), unit="agent-solves/s", solved=int(sum(r[0] for r in res)),
+                                  cpu_seconds_per_instance=round(float(np.mean([r[1] for r in res])), 4),
+                                  sample="value_all: the same %d instances, one process per core (%d processes, multiprocessing fork pool, wall clock "
+                                         "incl. pool start-up); value: the first %d of them on one thread" % (len(idx), procs, len(one)))
     except Exception as e:      # noqa: BLE001 -- reported, not fatal: the baseline above stands on its own
         out["third_party"] = dict(solver="scipy.optimize.milp (HiGHS)", error=str(e)[:200])
     out["note"] = "Gurobi at MIPGap=1e-2 (the reference's backend) is not installable here and was not measured"
     return out
+
+
+_HIGHS = {}
+
+
+def _highs_one(i):
+    """one instance of the CPU sample with scipy's HiGHS (worker of cpu_baseline's process pool); returns (solved, seconds)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import condense_np as cn
+    from scipy.optimize import milp, LinearConstraint, Bounds
+    sf = _HIGHS["raw"][int(_HIGHS["midx"][i])]
+    h = cn.rhs(sf["evo"], _HIGHS["x0"][i], _HIGHS["om"][i])
+    q = cn.lin_cost(sf["cost"], _HIGHS["x0"][i], _HIGHS["om"][i])
+    t0 = time.perf_counter()
+    r = milp(q, constraints=LinearConstraint(sf["G"], -np.inf, h), bounds=Bounds(sf["lb"], sf["ub"]),
+             integrality=sf["is_bin"].astype(int), options=dict(mip_rel_gap=_HIGHS["gap"]))
+    return int(r.x is not None), time.perf_counter() - t0
 
 
 def exact_leg(prob, x0, om, midx, n_exact, args):
@@ -207,6 +237,28 @@ class SideChannelGather(object):
         return np.stack([np.frombuffer(b, dtype=np.float64).reshape(loc.shape) for b in self.rd.all_gather_bytes(loc.tobytes())])
 
 
+def run_pipelined(probs, count, state, n_sets, gatherer):
+    """`count` steps over the handles `probs`: step j is launched on handle j % H as soon as that handle's previous step has been finished
+    (statistics, learnt queue order, result gather); returns the per-step statistics once every step has finished.  The order of
+    launches, finishes and gathers depends on (count, H) alone -- never on which solve happens to end first -- so every rank issues the
+    same sequence of collectives (tests/test_shard_gloo.py rehearses two ranks x two handles with stub problems)."""
+    H = len(probs)
+    res, pending = [None] * count, [None] * H
+    for j in range(count + H):
+        q = probs[j % H]
+        if pending[j % H] is not None:
+            res[pending[j % H]] = q.finish()
+            if gatherer is not None:
+                gatherer.gather_results(q)
+            pending[j % H] = None
+        if j < count:
+            q.select(state["k"] % n_sets)
+            state["k"] += 1
+            q.launch()
+            pending[j % H] = j
+    return res
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -215,8 +267,12 @@ def main():
     from pyhybridcontrol_amd import _lib, gpu, host
     from pyhybridcontrol_amd.batch import RcclGather, TcpRendezvous
     rd = TcpRendezvous() if world > 1 else None
-    _lib.check(_lib.load().mld_set_device(0 if args.rehearse else local_rank))
     agents, N_p, N_t, x0, om, midx = make_shard(args.agents, args.scenarios, rank * args.scenarios)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:
+        # CPU leg: rank 0 at N=1 only, and BEFORE the first HIP call of this process -- its HiGHS pool forks workers
+        cpu = cpu_baseline(agents, N_p, N_t, x0, om, midx, args.cpu_sample, args.mip_gap, args.node_limit, args.pivot_limit)
+    _lib.check(_lib.load().mld_set_device(0 if args.rehearse else local_rank))
     d = agents[0]["dims"]
     model = gpu.GpuModel([a["mats"] for a in agents], d)
     cost = host.stack_costs([host.cost_from_atoms(a["atoms"], d, N_p, N_t) for a in agents])
@@ -233,8 +289,7 @@ def main():
     om_sets = np.empty((n_sets,) + om.shape)
     x0_sets[0], om_sets[0] = x0, om
     for t in range(1, n_sets):
-        rng = np.random.Generator(np.random.PCG64([syn.CONFIGS["cfg4"]["seed"], 7919, rank, t]))
-        x0_sets[t], om_sets[t] = syn.make_scenarios(d["nx"], N_t, n_local, rng)
+        x0_sets[t], om_sets[t] = step_scenarios(rank, t, n_local)
     prob.stage(x0_sets, om_sets)
     # the timed steps alternate over `handles` problem handles on their own HIP streams (consecutive steps are independent scenario sets)
     H = max(1, args.handles)
@@ -269,6 +324,8 @@ def main():
     def step(closed_loop=False):
         if closed_loop:
             prob.advance()                          # next MPC step of the same scenarios: plant update + forecast shift, on device
+            if not args.closed_loop_cold:
+                prob.warm_start_from_previous(1)    # warm_start=True of the reference's solve(): the previous plan, moved on one step, as MIP start
         else:
             prob.select(state["k"] % n_sets)        # next scenario set: device-to-device copy
             state["k"] += 1
@@ -278,24 +335,9 @@ def main():
         return st
 
     def run_steps(count):
-        """`count` steps over the handles: step j is launched on handle j % H as soon as that handle's previous step has been finished
-        (statistics, learnt queue order, result gather); returns the per-step statistics once every step has finished"""
         if H == 1:
             return [step() for _ in range(count)]
-        res, pending = [None] * count, [None] * H
-        for j in range(count + H):
-            q = probs[j % H]
-            if pending[j % H] is not None:
-                res[pending[j % H]] = q.finish()
-                if gatherer is not None:
-                    gatherer.gather_results(q)
-                pending[j % H] = None
-            if j < count:
-                q.select(state["k"] % n_sets)
-                state["k"] += 1
-                q.launch()
-                pending[j % H] = j
-        return res
+        return run_pipelined(probs, count, state, n_sets, gatherer)
 
     run_steps(args.warmup)
     sync()
@@ -328,7 +370,7 @@ def main():
     io_bytes = 8.0 * n_local * (prob.n + prob.m + d["nx"] + prob.nW)           # SURVEY 8d input/output minimum
     achieved = upd_bytes / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    for name in ("r02_pmc_solve.json", "r01_pmc_solve.json"):
+    for name in ("r03_pmc_solve.json", "r02_pmc_solve.json", "r01_pmc_solve.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             try:
@@ -396,12 +438,20 @@ def main():
                       "tflops": round(flops / (rhs_ms * 1e-3) / 1e12, 3), "peak_tflops": 78.6,
                       "frac_of_peak": round(flops / (rhs_ms * 1e-3) / 1e12 / 78.6, 5),
                       "note": "fp64 matrix peak 78.6 TFLOP/s is AMD's MI355X figure (the guide lists 157.3 TFLOP/s for fp32 MFMA only); the launch moves "
-                              "%d MB of H + inputs + outputs, so it is bound by HBM / L2, not by the matrix cores" % int((64 * prob.m * (d["nx"] + prob.nW) * 8 + io_bytes) / 1e6)}
+                              "%d MB of H + inputs + outputs, so it is bound by HBM / L2, not by the matrix cores" % int((64 * prob.m * (d["nx"] + prob.nW) * 8 + io_bytes) / 1e6),
+                      "condensing": "K1 + K2 carry NO matrix-core work: the block products of the condensing have inner dimension nx = %d (<= 15 on every BASELINE shape), so a "
+                                    "16x16x4 MFMA tile would be > 75 %% padding for %.2f MFLOP per model against %.2f MB written -- the kernels are priced as the HBM write "
+                                    "stream they are (roofline_condense); the fp32 variant of configs[4] rounds the fp64 block arithmetic once on its way to HBM "
+                                    "(mld_condense_f32)" % (d["nx"], 2e-6 * N_t * (d["nx"] ** 2 * model.nv + d["nc"] * d["nx"] * model.nv), 8e-6 * N_t * (d["nc"] + d["nx"] + d["ny"]) * (N_t * model.nv + d["nx"] + N_t * d["nomega"] + 1))}
+    # the single-stream rate a closed-loop user gets (step k+1 of the SAME microgrids needs step k): beside `value` at top level
+    result["value_one_at_a_time"] = result["pipeline"]["value_one_at_a_time"]
     if exact is not None:
         result["value_exact"] = exact["value_exact"]
         result["exact"] = exact
-    # the same loop without the learnt longest-first queue (opts.reserved bit 3): one more step on the next instance set
+    # work queue: the SAME scenario set as the last reference step, once more in plain instance order (opts.reserved bit 3) -- identical
+    # instances, so the two kernel times differ by the queue order alone
     prob.set_opts(reserved=8 | args.reserved)
+    state["k"] -= 1
     sync()
     t0 = time.perf_counter()
     st_nl = step()
@@ -410,9 +460,10 @@ def main():
     if rd is not None:
         t_nl = rd.all_max(t_nl)
     prob.set_opts(reserved=args.reserved)
-    result["work_queue"] = {"value_learnt_order": result["pipeline"]["value_one_at_a_time"], "value_fifo_order": round(world * n_local / t_nl, 2),
-                            "note": "one launch at a time: longest-first order learnt from the previous step (other scenarios of the same agents) vs plain instance order (one extra step)",
-                            "kernel_ms_fifo": round(float(st_nl["solve_ms"]), 1)}
+    result["work_queue"] = {"kernel_ms_learnt": round(kernel_ms, 1), "kernel_ms_fifo": round(float(st_nl["solve_ms"]), 1),
+                            "learnt_over_fifo": round(float(st_nl["solve_ms"]) / kernel_ms, 4),
+                            "note": "the last reference step's scenario set solved twice, one launch at a time: with the longest-first order learnt from the previous step "
+                                    "(other scenarios of the same agents: agent-level information only) and in plain instance order; learnt_over_fifo > 1 = the learnt order is faster"}
     if args.closed_loop_steps > 0:
         # closed loop: the SAME scenarios advanced step by step (plant update with the inputs just computed, forecast shifted)
         rates, prov = [], []
@@ -427,8 +478,11 @@ def main():
             rates.append(round(world * n_local / t_c, 1))
             prov.append(round(st_c["n_optimal"] / n_local, 4))
         result["closed_loop"] = {"steps": args.closed_loop_steps, "value_per_step": rates, "proven_per_step": prov,
-                                 "note": "mld_advance_batch between solves (reference: sim_step_k -> lsim_k); the population drifts out of the seeded regime "
-                                         "(x0 in 55..64: most tanks need no heating inside the horizon) and the instances get harder (DESIGN section 6)"}
+                                 "value_last_step": rates[-1], "proven_last_step": prov[-1], "mip_start": not args.closed_loop_cold,
+                                 "note": "mld_advance_batch between solves (reference: sim_step_k -> lsim_k)%s; the population drifts out of the seeded regime "
+                                         "(x0 in 55..64: most tanks need no heating inside the horizon) towards its steady state and the instances get harder "
+                                         "(DESIGN section 6)" % ("" if args.closed_loop_cold else ", the previous plan moved on one step as MIP start "
+                                         "(mld_warm_start_from_previous: warm_start=True of controller_base.py:493,509-512)")}
     if rank == 0:
         # secondary roofline: condensing K1+K2 (SURVEY 8d formula: outputs + inputs), 64 models per launch
         ms = min(model.condense_device(N_t) for _ in range(5))
@@ -451,10 +505,7 @@ def main():
             result["roofline_condense"]["traffic"] = kb * 1024.0 if kb > 0 else None
         except Exception:
             result["roofline_condense"]["traffic"] = None
-        if world == 1 and not args.no_cpu and args.cpu_sample > 0:    # CPU leg: rank 0 at N=1 only
-            result["cpu_baseline"] = cpu_baseline(agents, N_p, N_t, x0, om, midx, args.cpu_sample, args.mip_gap, args.node_limit, args.pivot_limit)
-        else:
-            result["cpu_baseline"] = None
+        result["cpu_baseline"] = cpu            # (measured before the GPU part, see main())
         print(json.dumps(result), flush=True)
     if rd is not None:
         rd.close()

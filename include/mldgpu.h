@@ -194,6 +194,10 @@ int mld_upload_batch(mld_problem_t *, int batch, const int32_t *model_idx, const
  * col_rows (n_cols) = number of leading constraint rows column c applies to (NULL = all rows).  Valid until the
  * next mld_upload_batch; n_cols = 0 clears. */
 int mld_upload_constraint_blocks(mld_problem_t *, int n_cols, const double *omega_cols, const int32_t *col_rows);
+/* The same with the state every column was generated with: the reference's gen_evo_constraints accepts an explicit x_k instead of the
+ * controller's parameter (controllers/controller_base.py:411-416: `x_k = self._x_k if x_k is None else x_k`); the right-hand side of such a
+ * block is H_x x_cols + H_omega omega_col + H_5.  x_cols: batch x n_cols x nx, NULL = every column uses the instance's x0. */
+int mld_upload_constraint_blocks_x(mld_problem_t *, int n_cols, const double *omega_cols, const int32_t *col_rows, const double *x_cols);
 int mld_solve_resident(mld_problem_t *, mld_stats *stats_out);
 
 /* The resident solve in two halves, for callers that keep several problems busy (a fleet of independent microgrids: the reference solves

@@ -1,6 +1,7 @@
 """ORACLE (test infrastructure): golden OPTIMAL objectives of the benchmarked MILP instances, from a solver nobody here wrote.
 
-    python oracle/gen_solve_golden.py [--scen 32] [--cfg3 64] [--cfg5 32] [--procs 8]      # writes tests/golden/solve_cfg4_bench.npz, solve_cfg3.npz, solve_cfg5.npz
+    python oracle/gen_solve_golden.py [--scen 32] [--cfg3 64] [--cfg5 32] [--timed 16] [--closed-loop 256] [--procs 8]
+    # writes tests/golden/solve_cfg4_bench.npz, solve_cfg3.npz, solve_cfg5.npz, solve_cfg4_timed.npz, solve_cfg4_closed_loop.npz
 
 The reference hands its solve to cvxpy -> Gurobi (controllers/controller_base.py:509); neither is installable here.  The
 independent checker is scipy.optimize.milp (HiGHS) at mip_rel_gap = 0 on the ORIGINAL (un-tightened, un-scaled) rows that
@@ -46,6 +47,17 @@ def _init(kind, n_scen, gap=0.0, time_limit=120.0):
         import bench
         agents, N_p, N_t, x0, om, midx = bench.make_shard(64, n_scen, 0)
         _G.update(agents=agents, N_p=N_p, N_t=N_t, x0=x0, om=om, midx=midx, forms={})
+    elif kind == "timed":       # scenario set t = 1 of rank 0 of bench.py's timed region (the generator draws the whole shard at once)
+        import bench
+        agents, N_p, N_t, _, _, _ = bench.make_shard(64, 1, 0)
+        x0, om = bench.step_scenarios(0, 1, 64 * 512)
+        n = n_scen * 64
+        _G.update(agents=agents, N_p=N_p, N_t=N_t, x0=x0[:n], om=om[:n], midx=np.tile(np.arange(64, dtype=np.int32), n_scen), forms={})
+    elif kind == "closed_loop":  # inputs stored in the fixture itself (they are the result of a closed-loop simulation, not of a seed)
+        import bench
+        agents, N_p, N_t, _, _, _ = bench.make_shard(64, 1, 0)
+        z = np.load(os.path.join(ROOT, "tests", "golden", "closed_loop_cfg4_inputs.npz"))
+        _G.update(agents=agents, N_p=N_p, N_t=N_t, x0=z["x0"], om=z["omega"], midx=z["model_idx"].astype(np.int32), forms={})
     else:
         from pyhybridcontrol_amd import synthetic as syn
         wl = syn.make_workload(kind, batch=n_scen)
@@ -90,6 +102,10 @@ if __name__ == "__main__":
     ap.add_argument("--scen", type=int, default=16, help="scenarios of the cfg4 shard (x 64 agents)")
     ap.add_argument("--cfg3", type=int, default=64, help="cfg3 instances (agent 0 of make_workload('cfg3'))")
     ap.add_argument("--cfg5", type=int, default=0, help="cfg5 instances (n = 2303, 784 binaries; HiGHS at mip_rel_gap 1e-4 with a 240 s limit each: obj / dual_bound bracket the optimum also when the limit is hit)")
+    ap.add_argument("--timed", type=int, default=0, help="scenarios (x 64 agents) of bench.py's timed scenario set t = 1 of rank 0 -> solve_cfg4_timed.npz")
+    ap.add_argument("--closed-loop", type=int, default=0, help="instances of tests/golden/closed_loop_cfg4_inputs.npz (made by scripts/cpu_closed_loop.py --dump) -> solve_cfg4_closed_loop.npz")
+    ap.add_argument("--cfg5-gap", type=float, default=1e-4)
+    ap.add_argument("--cfg5-limit", type=float, default=240.0)
     ap.add_argument("--procs", type=int, default=8)
     args = ap.parse_args()
     gdir = os.path.join(ROOT, "tests", "golden")
@@ -98,4 +114,8 @@ if __name__ == "__main__":
     if args.cfg3 > 0:
         run("cfg3", args.cfg3, args.cfg3, args.procs, os.path.join(gdir, "solve_cfg3.npz"))
     if args.cfg5 > 0:
-        run("cfg5", args.cfg5, args.cfg5, args.procs, os.path.join(gdir, "solve_cfg5.npz"), gap=1e-4, time_limit=240.0)
+        run("cfg5", args.cfg5, args.cfg5, args.procs, os.path.join(gdir, "solve_cfg5.npz"), gap=args.cfg5_gap, time_limit=args.cfg5_limit)
+    if args.timed > 0:
+        run("timed", args.timed, args.timed * 64, args.procs, os.path.join(gdir, "solve_cfg4_timed.npz"))
+    if args.closed_loop > 0:
+        run("closed_loop", args.closed_loop, args.closed_loop, args.procs, os.path.join(gdir, "solve_cfg4_closed_loop.npz"))

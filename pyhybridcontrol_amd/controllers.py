@@ -131,11 +131,13 @@ class MldEvoMatrices(dict):
 class EvoConstraint(object):
     """numeric stand-in for the cvxpy constraint  LHS @ v <= RHS  returned by gen_evo_constraints"""
 
-    def __init__(self, H_v, rhs, omega_cols=None, rows=None, x_is_parameter=True):
+    def __init__(self, H_v, rhs, omega_cols=None, rows=None, x_is_parameter=True, x_problem=None):
         self.H_v, self.rhs = H_v, rhs
         # what the block was generated from: disturbance columns (N_tilde*nomega, S) padded to the full horizon, the
-        # number of constraint rows it spans, and whether x_k was the controller's parameter (updated at solve time)
+        # number of constraint rows it spans, and whether x_k was the controller's parameter (updated at solve time) or an
+        # explicit state (controller_base.py:411-416), kept in the GPU problem's state layout
         self.omega_cols, self.rows, self.x_is_parameter = omega_cols, rows, x_is_parameter
+        self.x_problem = x_problem
 
 
 class MldSimLog(dict):
@@ -223,6 +225,7 @@ class MpcController(object):
         self._rate_vars, self._rate_info, self._rate_dims, self._k_neg1 = [], {}, None, {}
         self._sense = 1.0
         self._solution = None
+        self._solution_problem, self._k_solved = None, None      # last solution in the GPU problem's layout (the MIP start of the next solve)
         self._x_k = np.zeros((info.nx, 1))
         self._omega_tilde_k = np.zeros((info.nomega * self._N_tilde, 1))
         if x_k is not None:
@@ -258,6 +261,7 @@ class MpcController(object):
         self._mld_evo_matrices = None
         if self._problem is not None:
             self._problem.close(); self._problem = None
+        self._solution_problem = None
         if getattr(self, "_epi_model", None) is not None:
             self._epi_model.close(); self._epi_model = None
         self._build_required = True
@@ -355,7 +359,8 @@ class MpcController(object):
         H_v = self.mld_evo_matrices.constraint["H_v_N_tilde"][:rows]
         h = h[self._orig_rows(self._N_tilde * info.n_constraints)]
         return EvoConstraint(H_v, h[:rows].reshape(-1, 1), omega_cols=np.array(cols, dtype=np.float64), rows=rows,
-                             x_is_parameter=x_is_parameter)
+                             x_is_parameter=x_is_parameter,
+                             x_problem=None if x_is_parameter else np.array(self._x_problem(x_k), dtype=np.float64).reshape(-1))
 
     def set_constraints(self, std_evo_constaints=ParNotSet, other_constraints=ParNotSet, disable_soft_constraints=False):
         """controller_base.py:457-475.  `other_constraints`: blocks from gen_evo_constraints (scenario columns, min / max
@@ -368,8 +373,6 @@ class MpcController(object):
             for b in blocks:
                 if not isinstance(b, EvoConstraint) or b.omega_cols is None:
                     raise TypeError("other_constraints must come from gen_evo_constraints()")
-                if not b.x_is_parameter:
-                    raise NotImplementedError("constraint blocks generated with an explicit x_k")
             self._other_constraints = blocks
         # mu == 0 (controller_base.py:466-471): extra model rows mu <= 0, see epigraph.hard_block
         self._no_soft = bool(disable_soft_constraints and self.mld_info_k.nmu)
@@ -426,6 +429,7 @@ class MpcController(object):
         if self._problem is not None and sig != getattr(self, "_epi_sig", ()):
             self._problem.close()                    # the set of augmenting atoms changed: another augmented model
             self._problem = None
+            self._solution_problem = None
             if getattr(self, "_epi_model", None) is not None:
                 self._epi_model.close()
                 self._epi_model = None
@@ -508,8 +512,12 @@ class MpcController(object):
     # -- solve -------------------------------------------------------------------------------------
     def solve(self, k, x_k=None, omega_tilde_k=None, external_solve=None, solver=None, verbose=False, warm_start=True,
               parallel=False, *args, method=None, **kwargs):
-        """controller_base.py:491-540.  `solver`, `warm_start`, `parallel`, `method` are accepted for
-        signature compatibility and ignored; Gurobi-style kwargs MIPGap / NodeLimit are honoured."""
+        """controller_base.py:491-540.  `solver`, `parallel`, `method` are accepted for signature compatibility and ignored
+        (there is one backend); the Gurobi-style kwargs MIPGap / NodeLimit / IterationLimit / TimeLimit the reference forwards
+        (micro_grid_control_simulation.py:232) are honoured per call, TimeLimit as seconds of device time per instance.
+        `warm_start` (default True, forwarded by the reference to its backend, :493,509-512): the previous solution's binaries are the
+        MIP start of this solve, moved on by k - k_previous steps when both are integers (the receding-horizon shift; 0 for a
+        re-solve of the same step)."""
         start = time.time()
         try:
             if x_k is not None:
@@ -524,27 +532,41 @@ class MpcController(object):
                 return external_solve
             remap = {}
             for key, val in kwargs.items():
-                if key in ("MIPGap", "NodeLimit", "IterationLimit"):
+                if key in ("MIPGap", "NodeLimit", "IterationLimit", "TimeLimit"):
                     remap[key] = val
-                elif key not in ("TimeLimit",):
+                else:
                     raise TypeError("unsupported solver option %r" % key)
             # Gurobi-style kwargs are PER CALL, as in the reference (they go straight to Problem.solve, controller_base.py:509): the
             # limits of the existing problem are set without a rebuild and fall back to the constructor's options afterwards
-            names = dict(MIPGap="gap_rel", NodeLimit="max_nodes", IterationLimit="max_pivots")
+            names = dict(MIPGap="gap_rel", NodeLimit="max_nodes", IterationLimit="max_pivots", TimeLimit="time_limit")
             ctor = gpu.make_opts(**self._solver_opts)
-            eff = {k2: getattr(ctor, k2) for k2 in ("gap_rel", "max_nodes", "max_pivots", "gap_abs")}
+            eff = {k2: getattr(ctor, k2) for k2 in ("gap_rel", "max_nodes", "max_pivots", "gap_abs", "time_limit")}
             eff.update({names[k2]: v2 for k2, v2 in remap.items()})
             cur = self._problem.opts
             if any(getattr(cur, k2) != type(getattr(cur, k2))(v2) for k2, v2 in eff.items()):
                 self._problem.set_opts(**eff)
             try:
-                cols = rows = None
+                cols = rows = xcols = None
                 if getattr(self, "_other_constraints", None):
                     cols = np.hstack([b.omega_cols for b in self._other_constraints]).T[np.newaxis]
                     nc = self.mld_info_k.n_constraints
                     nc_p = self._epi_dims["nc"] if self._epi_blocks else nc
                     rows = np.concatenate([np.full(b.omega_cols.shape[1], (b.rows // nc) * nc_p) for b in self._other_constraints])
-                out = self._problem.solve(self._x_problem().T, self._omega_tilde_k.T, omega_cols=cols, col_rows=rows)
+                    if any(not b.x_is_parameter for b in self._other_constraints):
+                        xp = self._x_problem().reshape(-1)       # blocks generated with an explicit x_k keep it; the others follow the parameter
+                        xcols = np.vstack([np.tile((xp if b.x_is_parameter else b.x_problem), (b.omega_cols.shape[1], 1))
+                                           for b in self._other_constraints])[np.newaxis]
+                mip_start = None
+                if warm_start and self._solution_problem is not None:
+                    shift = 0
+                    if isinstance(k, (int, np.integer)) and isinstance(self._k_solved, (int, np.integer)):
+                        shift = max(0, int(k) - int(self._k_solved))
+                    V = self._solution_problem.reshape(self._N_tilde, -1)
+                    if shift:
+                        V = np.vstack([V[min(shift, self._N_tilde - 1):], np.repeat(V[-1:], min(shift, self._N_tilde - 1), axis=0)])
+                    mip_start = V.reshape(1, -1)
+                out = self._problem.solve(self._x_problem().T, self._omega_tilde_k.T, omega_cols=cols, col_rows=rows, x_cols=xcols,
+                                          warm_start=mip_start)
             except MldGpuError as e:
                 self._solve_time_solver = np.nan
                 raise ControllerSolverError(str(e)) from e
@@ -556,6 +578,7 @@ class MpcController(object):
             if not np.isfinite(solution):
                 raise ControllerSolverError("solve() failed with objective: '%s', and status: %s" % (solution, status))
             v = out["v"][0]
+            self._solution_problem, self._k_solved = np.array(v, dtype=np.float64), k
             self._solution = (v if self._vmap is None else v[self._vmap]).reshape(-1, 1)
             self._status = status
             return solution

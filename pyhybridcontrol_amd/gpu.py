@@ -202,9 +202,10 @@ class GpuProblem(object):
         self.batch = batch
         return batch
 
-    def upload_constraint_blocks(self, omega_cols, col_rows=None):
-        """extra constraint blocks for the uploaded batch (mld_upload_constraint_blocks): omega_cols (batch, n_cols,
-        N_tilde*nomega), col_rows (n_cols) leading rows each column constrains (None = all); None / empty clears"""
+    def upload_constraint_blocks(self, omega_cols, col_rows=None, x_cols=None):
+        """extra constraint blocks for the uploaded batch (mld_upload_constraint_blocks_x): omega_cols (batch, n_cols,
+        N_tilde*nomega), col_rows (n_cols) leading rows each column constrains (None = all), x_cols (batch, n_cols, nx) the state
+        each column was generated with (None = the instance's x0); None / empty clears"""
         if omega_cols is None or np.size(omega_cols) == 0:
             check(_lib.load().mld_upload_constraint_blocks(self._h, 0, None, None))
             return 0
@@ -213,8 +214,11 @@ class GpuProblem(object):
         cr = None
         if col_rows is not None:
             cr = np.ascontiguousarray(col_rows, dtype=np.int32).reshape(n_cols)
-        check(_lib.load().mld_upload_constraint_blocks(self._h, n_cols, _lib.dptr(cols),
-                                                       cr.ctypes.data_as(C.POINTER(C.c_int32)) if cr is not None else None))
+        nx = self.model.dims["nx"]
+        xc = _lib.as_f64(x_cols).reshape(self.batch, n_cols, nx) if (x_cols is not None and nx) else None
+        check(_lib.load().mld_upload_constraint_blocks_x(self._h, n_cols, _lib.dptr(cols),
+                                                         cr.ctypes.data_as(C.POINTER(C.c_int32)) if cr is not None else None,
+                                                         _lib.dptr(xc) if xc is not None else None))
         return n_cols
 
     def set_opts(self, **opts):
@@ -312,10 +316,12 @@ class GpuProblem(object):
         check(_lib.load().mld_download_telemetry(self._h, ip(lat), ip(rows), C.byref(rb)))
         return dict(latency_ns=lat, rows_updated=rows, row_bytes=int(rb.value))
 
-    def solve(self, x0, omega, model_idx=None, fixed_bin=None, omega_cols=None, col_rows=None):
+    def solve(self, x0, omega, model_idx=None, fixed_bin=None, omega_cols=None, col_rows=None, x_cols=None, warm_start=None):
         self.upload(x0, omega, model_idx, fixed_bin)
         if omega_cols is not None:
-            self.upload_constraint_blocks(omega_cols, col_rows)
+            self.upload_constraint_blocks(omega_cols, col_rows, x_cols)
+        if warm_start is not None:
+            self.set_warm_start(warm_start)
         stats = self.solve_resident()
         out = self.download()
         out["stats"] = stats

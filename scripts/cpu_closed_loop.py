@@ -95,6 +95,10 @@ def main():
                 om[i] = np.roll(W, -1, axis=0).ravel()
                 newplan.append(np.vstack([V[1:], V[-1:]]).ravel())
             plan = newplan
+    if os.environ.get("CL_DUMP"):      # steady-state inputs as a fixture: tests/golden/closed_loop_cfg4_inputs.npz
+        np.savez_compressed(os.environ["CL_DUMP"], x0=x0, omega=om, model_idx=midx[:n].astype(np.int16), steps=np.array(steps),
+                            note=np.array("inputs of the first %d instances of the cfg4 shard after %d closed-loop MPC steps (oracle at MIPGap %g / NodeLimit %d, "
+                                          "plant = control model, forecast rotated): scripts/cpu_closed_loop.py" % (n, steps, gap, nodes)))
     h = np.array(hist)
     print("[%s] mean over steps: proven %.2f%% nodes %.1f pivots %.1f work %.0f | last 8 steps: proven %.2f%% pivots %.1f work %.0f" % (
         tag, h[:, 0].mean(), h[:, 1].mean(), h[:, 2].mean(), h[:, 3].mean(), h[-8:, 0].mean(), h[-8:, 2].mean(), h[-8:, 3].mean()))

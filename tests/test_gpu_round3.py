@@ -1,0 +1,313 @@
+"""Round-3 behaviour of the solve path, through the C ABI:
+
+* MIP start (warm_start=True of the reference's solve(), controllers/controller_base.py:493,509-512) and TimeLimit
+  (micro_grid_control_simulation.py:232) are honoured;
+* mld_advance_batch2 skips instances without a usable plan and refuses what it cannot do;
+* constraint blocks generated with an explicit x_k (controller_base.py:411-416);
+* handle-state rules (launch / finish, selection on a private stream, fixed flags);
+* the benchmark's TIMED scenario set and steady-state closed-loop instances against committed HiGHS optima.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import bench
+import condense_np as cn
+from pyhybridcontrol_amd import MldGpuError, _lib, gpu, host, synthetic as syn
+from test_gpu_bench_parity import _check_against_optimum
+
+pytestmark = pytest.mark.gpu
+
+GDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GAP, NODES, PIVOTS = 1e-2, 800, 40000          # bench.py defaults
+
+
+def _shard_problem(n_scen, **opts):
+    agents, N_p, N_t, x0, om, midx = bench.make_shard(64, n_scen, 0)
+    d = agents[0]["dims"]
+    model = gpu.GpuModel([a["mats"] for a in agents], d)
+    cost = host.stack_costs([host.cost_from_atoms(a["atoms"], d, N_p, N_t) for a in agents])
+    return agents, N_p, N_t, x0, om, midx, model, gpu.GpuProblem(model, N_p, N_t, cost, **opts)
+
+
+def test_timed_scenario_set_against_highs_optimum():
+    """the scenario sets of bench.py's TIMED region had no golden.  First 1024 instances of set t = 1 of rank 0
+    (bench.step_scenarios) at the bench's options against HiGHS optima (tests/golden/solve_cfg4_timed.npz)."""
+    gold = np.load(os.path.join(GDIR, "solve_cfg4_timed.npz"))
+    n = int(gold["n_scen"]) * 64
+    assert np.all(gold["proven"][:n] == 1)
+    agents, N_p, N_t, _, _, _, model, prob = _shard_problem(1, gap_rel=GAP, max_nodes=NODES, max_pivots=PIVOTS)
+    x0, om = bench.step_scenarios(0, 1, 64 * 512)
+    midx = np.tile(np.arange(64, dtype=np.int32), n // 64)
+    out = prob.solve(x0[:n], om[:n], midx)
+    prob.close(); model.close()
+    rel = _check_against_optimum(out, gold["obj"][:n], GAP)
+    proven, within = float((out["status"] == 0).mean()), float((rel <= GAP + 1e-9).mean())
+    print("timed set: proven %.4f within-gap %.4f worst %.4f node-limited %d" % (proven, within, rel.max(), int((out["status"] == 2).sum())))
+    assert proven >= 0.99 and within >= 0.995
+    assert rel.max() <= 0.06, "an incumbent more than 6 %% above the optimum: %g" % rel.max()
+
+
+def test_steady_state_closed_loop_instances_against_highs_optimum():
+    """the closed loop drifts to harder instances than the seeded distribution: 256 steady-state inputs
+    (tests/golden/closed_loop_cfg4_inputs.npz, 20 closed-loop steps of scripts/cpu_closed_loop.py) with their HiGHS optima"""
+    z = np.load(os.path.join(GDIR, "closed_loop_cfg4_inputs.npz"))
+    gold = np.load(os.path.join(GDIR, "solve_cfg4_closed_loop.npz"))
+    ok = gold["proven"] == 1
+    assert ok.mean() >= 0.95
+    agents, N_p, N_t, _, _, _, model, prob = _shard_problem(1, gap_rel=GAP, max_nodes=NODES, max_pivots=PIVOTS)
+    out = prob.solve(z["x0"], z["omega"], z["model_idx"].astype(np.int32))
+    prob.close(); model.close()
+    sub = {k: v[ok] for k, v in out.items() if isinstance(v, np.ndarray) and v.shape[:1] == ok.shape}
+    rel = _check_against_optimum(sub, gold["obj"][ok], GAP)
+    proven, within = float((out["status"] == 0).mean()), float((rel <= GAP + 1e-9).mean())
+    print("steady state: proven %.4f within-gap %.4f worst %.4f" % (proven, within, rel.max()))
+    assert proven >= 0.93 and within >= 0.96
+    assert rel.max() <= 0.10
+
+
+def test_mip_start_keeps_the_answer_and_is_used_lazily():
+    """closed loop on device with and without the shifted previous plan as MIP start: every proven objective of both runs is
+    within the gap of the same HiGHS-checked optimum (they solve identical instances), a start never makes an instance lose
+    its incumbent, and an instance that is proven at the root does not pay for the start (same pivots)."""
+    from scipy.optimize import Bounds, LinearConstraint, milp
+    agents, N_p, N_t, x0, om, midx, model, prob = _shard_problem(4, gap_rel=GAP, max_nodes=NODES, max_pivots=PIVOTS)
+    prob.upload(x0, om, midx)
+    prob.solve_resident()
+    for _ in range(3):                        # a few steps into the closed loop
+        assert prob.advance() == 0
+        prob.solve_resident()
+    assert prob.advance() == 0
+    xk, wk = prob.inputs()
+    prob.solve_resident(); cold = prob.download()
+    # the same inputs again, now with the previous plan (one step back in time) as start: re-create that state exactly
+    prob2 = gpu.GpuProblem(model, N_p, N_t, host.stack_costs([host.cost_from_atoms(a["atoms"], agents[0]["dims"], N_p, N_t) for a in agents]),
+                           gap_rel=GAP, max_nodes=NODES, max_pivots=PIVOTS)
+    prob2.upload(xk, wk, midx)
+    V = cold["v"].reshape(len(midx), N_t, -1)
+    prob2.set_warm_start(V.reshape(len(midx), -1))       # shift 0: the solution of these very inputs -- the best possible start
+    prob2.solve_resident(); warm = prob2.download()
+    assert np.all(np.isfinite(warm["obj"]))
+    # same instances: both answers are feasible points and valid bounds of the same optimum
+    assert np.all(warm["lower_bound"] <= cold["obj"] + 1e-6 * np.maximum(1.0, np.abs(cold["obj"])))
+    assert np.all(cold["lower_bound"] <= warm["obj"] + 1e-6 * np.maximum(1.0, np.abs(warm["obj"])))
+    easy = (cold["status"] == 0) & (cold["nodes"] <= 2)
+    assert easy.sum() > 0 and np.array_equal(warm["pivots"][easy], cold["pivots"][easy]), "an instance proven at the root must not pay for the start"
+    assert (warm["status"] == 0).sum() >= (cold["status"] == 0).sum() - 2
+    # the hardest instances against HiGHS: the start's answer is within the gap when proven
+    raw = {}
+    worst = np.argsort(-cold["nodes"])[:6]
+    for i in worst:
+        a = int(midx[i])
+        if a not in raw:
+            raw[a] = cn.standard_form(agents[a]["mats"], agents[a]["atoms"], N_p, N_t, nu_l=agents[a]["dims"]["nu_l"])
+        sf = raw[a]
+        h, q = cn.rhs(sf["evo"], xk[i], wk[i]), cn.lin_cost(sf["cost"], xk[i], wk[i])
+        r = cn.cost_const(sf["cost"]["const_terms"], xk[i], wk[i])
+        ref = milp(q, constraints=LinearConstraint(sf["G"], -np.inf, h), integrality=sf["is_bin"].astype(int), bounds=Bounds(sf["lb"], sf["ub"]),
+                   options=dict(mip_rel_gap=0, time_limit=120))
+        if ref.status != 0:
+            continue
+        opt = ref.fun + r
+        for o in (cold, warm):
+            assert o["obj"][i] >= opt - 1e-6 * max(1.0, abs(opt)) and o["lower_bound"][i] <= opt + 1e-6 * max(1.0, abs(opt))
+            if o["status"][i] == 0:
+                assert o["obj"][i] - opt <= GAP * abs(o["obj"][i]) + 1e-6
+    # device-built start after an advance: accepted, and cleared by the next upload
+    prob.advance(); prob.warm_start_from_previous(1); prob.solve_resident()
+    dev = prob.download()
+    assert np.all(np.isfinite(dev["obj"]))
+    prob.close(); prob2.close(); model.close()
+
+
+def test_time_limit_ends_the_search_like_the_node_limit():
+    agents, N_p, N_t, x0, om, midx, model, prob = _shard_problem(2, gap_rel=1e-6, max_nodes=20000, max_pivots=400000)
+    gold = np.load(os.path.join(GDIR, "solve_cfg4_bench.npz"))["obj"][:128]
+    prob.set_opts(TimeLimit=0.02)                        # 20 ms of device time per instance
+    out = prob.solve(x0, om, midx)
+    tel = prob.telemetry()
+    rel = _check_against_optimum(out, gold, 1e-6)
+    assert (out["status"] == 2).sum() >= 1, "at gap 1e-6 some of these instances need far more than 20 ms"
+    # an instance ends within the limit plus the work it cannot interrupt (its root LP and cut loop, one node, the rescue dive)
+    lim = out["status"] == 2
+    assert tel["latency_ns"][lim].max() * 1e-9 <= 0.5, tel["latency_ns"][lim].max() * 1e-9
+    assert np.all(np.isfinite(out["obj"])), "a timed-out instance still returns an incumbent"
+    prob.set_opts(TimeLimit=0.0)
+    full = prob.solve(x0, om, midx)
+    assert (full["status"] == 0).sum() > (out["status"] == 0).sum()
+    prob.set_opts(TimeLimit=3600.0)                      # a limit nobody reaches changes nothing
+    same = prob.solve(x0, om, midx)
+    assert np.array_equal(same["obj"], full["obj"]) and np.array_equal(same["status"], full["status"]) and np.array_equal(same["pivots"], full["pivots"])
+    prob.close(); model.close()
+
+
+def test_advance_skips_instances_without_a_plan_and_refuses_what_it_cannot_do():
+    wl = syn.make_workload("cfg2", batch=8)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    m = gpu.GpuModel([ag["mats"]], d)
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"]), gap_rel=1e-2, max_nodes=400)
+    p.upload(ag["x0"], ag["omega"])
+    with pytest.raises(MldGpuError):
+        p.advance()                                      # nothing solved since the upload: no plan to apply
+    p.set_opts(max_pivots=3)                             # the root LP cannot finish: NUMERICAL, no incumbent
+    p.solve_resident()
+    bad = p.download()
+    assert np.all(bad["status"] == 3) and not np.any(np.isfinite(bad["obj"]))
+    assert p.advance() == 8
+    x1, w1 = p.inputs()
+    assert np.array_equal(x1, ag["x0"]) and np.array_equal(w1, ag["omega"]), "instances without a plan keep state and forecast"
+    p.set_opts(max_pivots=50000)
+    p.solve_resident()
+    assert p.advance() == 0
+    x2, _ = p.inputs()
+    assert not np.array_equal(x2, ag["x0"])
+    # active soft constraints in step 0: the tank model's delta / z do not drive the state (B2 = B3 = 0), so the planned
+    # auxiliaries and the ones lsim_k re-derives from (x, u, omega) give the same x(k+1) -- the documented equivalence condition
+    cold = ag["x0"].copy(); cold[:, 0] = 45.0             # below T_min: the lower soft constraint of tank 0 is active whatever happens
+    out = p.solve(cold, ag["omega"])
+    nv = m.nv
+    mu0 = out["v"][:, d["nu"] + d["ndelta"] + d["nz"]:nv]
+    assert (mu0 > 1e-6).any(), "the test needs active slack in step 0"
+    assert p.advance() == 0
+    x3, _ = p.inputs()
+    mats = cn.pad_mats(ag["mats"], cn.mld_dims(ag["mats"]))
+    for b in range(8):
+        u = out["v"][b][:d["nu"]]
+        w0 = ag["omega"][b].reshape(wl["N_tilde"], d["nomega"])[0]
+        ref = mats["A"] @ cold[b] + mats["B1"] @ u + mats["B4"] @ w0 + mats["b5"][:, 0]      # lsim_k with u only: delta / z re-derived, not needed for x+
+        assert np.allclose(x3[b], ref, rtol=1e-13, atol=1e-12)
+    p.close(); m.close()
+
+
+def test_advance_refuses_time_varying_models():
+    import _tv
+    wl = syn.make_workload("cfg1", batch=4)
+    ag = wl["agents"][0]
+    d, N = ag["dims"], wl["N_tilde"]
+    m = gpu.GpuModel([_tv.step_models(ag["mats"], N, seed=21, strength=0.05)], d, time_varying=True)
+    p = gpu.GpuProblem(m, wl["N_p"], N, host.cost_from_atoms(ag["atoms"], d, wl["N_p"], N), max_nodes=2000)
+    p.solve(ag["x0"], ag["omega"])
+    with pytest.raises(MldGpuError):
+        p.advance()                                      # the step models would have to shift with the horizon
+    p.close(); m.close()
+
+
+def test_explicit_state_constraint_blocks():
+    """gen_evo_constraints(x_k=...) blocks (controller_base.py:411-416): the right-hand side of such a block is built from ITS state, not
+    from the controller's parameter; checked against numpy on the condensed maps and against the row-wise minimum the solve must respect"""
+    import pyhybridcontrol_amd as phc
+    model = phc.MldModel(A=[[0.9970371127900564]], B1=[[4.298192277481107]], B4=[[-179.73320827515]],
+                         b5=[[0.07407218024859108]], E=[[1], [-1]], F1=[[0], [0]], Psi=[[-1, 0], [0, -1]],
+                         f5=[[65.0], [-50.0]], nu_l=1, ts=900)
+    price = np.array([1, 3, 3, 1, 1.0])
+    om = np.array([.004, .012, 0, .009, .002]).reshape(-1, 1)
+    ctrl = phc.MpcController(model, N_p=4)
+    ctrl.set_std_obj_atoms(q_u=(price * 0.75).reshape(-1, 1), q_mu=[90.0, 90.0])
+    ctrl.x_k, ctrl.omega_tilde_k = [55.0], om
+    blk = ctrl.gen_evo_constraints(x_k=[50.3], omega_tilde_k=om * 1.5)          # a colder tank with heavier draws: binds harder than the standard block
+    evo = ctrl.mld_evo_matrices.constraint
+    ref = evo["H_x_N_tilde"] @ np.array([[50.3]]) + evo["H_omega_N_tilde"] @ (om * 1.5) + evo["H_5_N_tilde"]
+    assert np.allclose(blk.rhs, ref, rtol=1e-12, atol=1e-12) and not blk.x_is_parameter
+    ctrl.set_constraints(other_constraints=[blk])
+    ctrl.build()
+    obj_blk = ctrl.solve(0)
+    v = ctrl.v_N_tilde
+    h_std = evo["H_x_N_tilde"] @ ctrl.x_k + evo["H_omega_N_tilde"] @ om + evo["H_5_N_tilde"]
+    assert np.all(evo["H_v_N_tilde"] @ v <= np.minimum(h_std, ref) + 1e-7), "the solution must satisfy both blocks"
+    plain = phc.MpcController(model, N_p=4)
+    plain.set_std_obj_atoms(q_u=(price * 0.75).reshape(-1, 1), q_mu=[90.0, 90.0])
+    plain.build()
+    obj_plain = plain.solve(0, x_k=[55.0], omega_tilde_k=om)
+    assert obj_blk >= obj_plain - 1e-9 and obj_blk > obj_plain + 1e-6, "the colder block must cost something"
+    # the block keeps ITS state when the parameter moves
+    obj_moved = ctrl.solve(1, x_k=[60.0])
+    h_std2 = evo["H_x_N_tilde"] @ np.array([[60.0]]) + evo["H_omega_N_tilde"] @ om + evo["H_5_N_tilde"]
+    assert np.all(evo["H_v_N_tilde"] @ ctrl.v_N_tilde <= np.minimum(h_std2, ref) + 1e-7)
+    assert np.isfinite(obj_moved)
+
+
+def test_controller_honours_warm_start_and_time_limit():
+    import pyhybridcontrol_amd as phc
+    wl = syn.make_workload("cfg2", batch=1)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    model = phc.MldModel(nu_l=d["nu_l"], ts=900, **{k: v for k, v in ag["mats"].items()})
+    ctrl = phc.MpcController(model, N_p=wl["N_p"])
+    ctrl.set_std_obj_atoms(**ag["atoms"])
+    ctrl.build()
+    a = ctrl.solve(0, x_k=ag["x0"][0], omega_tilde_k=ag["omega"][0], MIPGap=1e-6, NodeLimit=20000)
+    b = ctrl.solve(0, MIPGap=1e-6, NodeLimit=20000, warm_start=True)          # re-solve of the same step: the start is the optimum itself
+    c = ctrl.solve(0, MIPGap=1e-6, NodeLimit=20000, warm_start=False)
+    assert abs(a - b) <= 1e-6 * max(1.0, abs(a)) and abs(a - c) <= 1e-6 * max(1.0, abs(a))
+    t = ctrl.solve(1, MIPGap=1e-6, NodeLimit=20000, TimeLimit=1e-5)            # far too short to prove: still an answer, shifted start in use
+    assert np.isfinite(t) and t >= a - 1e-6 * max(1.0, abs(a))
+    assert ctrl._problem.opts.time_limit == pytest.approx(1e-5)
+    ctrl.solve(1)
+    assert ctrl._problem.opts.time_limit == 0.0, "per-call kwargs must not persist"
+    with pytest.raises(TypeError):
+        ctrl.solve(1, Threads=4)
+
+
+def test_selection_on_a_private_stream_is_visible_to_the_next_call():
+    """mld_select_inputs queued its copies on the problem's non-blocking stream and returned; a following download ran on
+    the legacy stream and could read stale data"""
+    agents, N_p, N_t, x0, om, midx, model, prob = _shard_problem(2, gap_rel=GAP, max_nodes=50)
+    prob.upload(x0, om, midx)
+    rng = np.random.default_rng(5)
+    xs = np.stack([x0 + k for k in range(3)])
+    ws = np.stack([om * (1.0 + 0.01 * k) + rng.normal(size=om.shape) * 0 for k in range(3)])
+    prob.stage(xs, ws)
+    prob.use_stream()
+    for k in (2, 0, 1, 2):
+        prob.select(k)
+        xa, wa = prob.inputs()
+        assert np.array_equal(xa, xs[k]) and np.array_equal(wa, ws[k]), k
+    prob.close(); model.close()
+
+
+def test_handle_state_rules():
+    wl = syn.make_workload("cfg2", batch=16)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    m = gpu.GpuModel([ag["mats"]], d)
+    cost = host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"])
+    p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost, gap_rel=1e-2, max_nodes=200)
+    with pytest.raises(TypeError):
+        p.set_opts(flags=_lib.MLD_F32)                     # flags decide how the cost is assembled: fixed at creation
+    o = gpu.make_opts(gap_rel=1e-2, max_nodes=200, flags=_lib.MLD_F32)
+    import ctypes as C
+    assert _lib.load().mld_problem_set_opts(p._h, C.byref(o)) != 0      # the C entry refuses it too
+    # relaxation-only batch on the LDS-resident kernel: its launch completes inside mld_solve_launch, but the handle stays in flight until the
+    # matching finish (in that window an upload used to be accepted and the later finish reported another solve)
+    fixed = np.zeros((16, p.n_bin), np.uint8)
+    p.upload(ag["x0"], ag["omega"], fixed_bin=fixed)
+    p.launch()
+    with pytest.raises(MldGpuError):
+        p.upload(ag["x0"], ag["omega"])
+    st = p.finish()
+    assert st["n_optimal"] + st["n_infeasible"] + st["n_node_limit"] + st["n_numerical"] == 16
+    with pytest.raises(MldGpuError):
+        p.finish()                                        # no launch to finish
+    p.upload(ag["x0"], ag["omega"])                      # and the handle is usable again
+    p.solve_resident()
+    p.close(); m.close()
+
+
+def test_fp32_condensing_at_the_cfg5_shape():
+    """configs[4] ("N=48, 16 binaries/step ... fp32 condensing"): mld_condense_f32 at n_h = 15, N_tilde = 49 against the fp64 oracle"""
+    wl = syn.make_workload("cfg5", batch=1)
+    ag = wl["agents"][0]
+    m = gpu.GpuModel([ag["mats"]], ag["dims"])
+    N = wl["N_tilde"]
+    ref = cn.condense(ag["mats"], N)
+    f32 = m.condense(N, dtype=np.float32)
+    f64 = m.condense(N)
+    for k in ("Phi_x", "Gamma_v", "Gamma_omega", "Gamma_5", "L_v", "H_x", "H_v", "H_omega", "H_5"):
+        scale = max(1.0, np.abs(ref[k]).max())
+        assert np.abs(f64[k][0] - ref[k]).max() / scale < 1e-11, k
+        assert f32[k].dtype == np.float32
+        assert np.array_equal(f32[k][0], f64[k][0].astype(np.float32)), "%s: the fp32 output is the fp64 arithmetic rounded once" % k
+        assert np.abs(f32[k][0].astype(np.float64) - ref[k]).max() / scale < 1e-6, k
+    m.close()

@@ -210,3 +210,94 @@ def test_oracle_against_highs_golden_on_bench_instances():
         proven = r["status"] == 0
         assert proven.sum() >= n - 2
         assert np.all(obj[proven] - opt[proven] <= gap * np.abs(obj[proven]) + 1e-6 * scale[proven])
+
+
+# ---- round 3: MIP start, anti-stalling perturbation, new fixtures -----------------------------------------------
+
+def _bench_instance(i):
+    import bench
+    agents, N_p, N_t, x0, om, midx = bench.make_shard(64, i // 64 + 1, 0)
+    ag = agents[int(midx[i])]
+    d = ag["dims"]
+    sf = cn.standard_form(tighten_np.tighten(ag["mats"], d, nu_l=d["nu_l"]), ag["atoms"], N_p, N_t, nu_l=d["nu_l"])
+    return sf, cn.lin_cost(sf["cost"], x0[i], om[i]), cn.rhs(sf["evo"], x0[i], om[i]), cn.cost_const(sf["cost"]["const_terms"], x0[i], om[i])
+
+
+def test_mip_start_never_changes_the_proven_optimum():
+    """orc_solve_miqp_start: the start is only ever an incumbent candidate (the reference forwards warm_start=True to its backend,
+    controller_base.py:493,509-512) -- the optimum, a wrong start, an infeasible-looking start all end at the same proven value"""
+    sf, q, h = _instance("cfg2", 1, tight=True)
+    kw = dict(gap_rel=0.0, max_nodes=100000, presolve=0)
+    ref = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], **kw)
+    assert ref["status"] == "optimal"
+    rng = np.random.default_rng(3)
+    for start in (ref["x"], np.zeros_like(ref["x"]), np.ones_like(ref["x"]), rng.integers(0, 2, ref["x"].size).astype(float)):
+        r = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], x_start=start, **kw)
+        assert r["status"] == "optimal" and abs(r["obj"] - ref["obj"]) <= 1e-9 * max(1.0, abs(ref["obj"]))
+
+
+def test_mip_start_is_evaluated_lazily():
+    """an instance the deepening passes close by themselves never pays for the start (identical pivots); on one that reaches the
+    dive, a good start is taken as the incumbent"""
+    sf, q, h, _ = _bench_instance(98)              # proven at the root
+    kw = dict(gap_rel=1e-2, max_nodes=800, presolve=0, max_pivots=40000)
+    a = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], **kw)
+    b = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], x_start=np.zeros(q.size), **kw)
+    assert a["nodes"] <= 2 and b["pivots"] == a["pivots"] and b["obj"] == a["obj"]
+
+
+def test_cost_perturbation_breaks_the_stall_and_keeps_the_value():
+    """bench instance 1907 (PV surplus in 20 of 25 steps: dual degenerate): without the perturbation one cut round stalls for
+    > 2000 Bland pivots and the root is rebuilt without cuts; with it the same optimum costs a fraction of the pivots"""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0] = [%r, %r, %r]; import test_oracle_solver as t, orc\n"
+            "sf, q, h, r = t._bench_instance(1907)\n"
+            "o = orc.solve_milp(q, sf['G'], h, sf['lb'], sf['ub'], sf['is_bin'], gap_rel=1e-2, max_nodes=800, presolve=0, max_pivots=40000)\n"
+            "print(o['status'], repr(o['obj'] + r), o['pivots'], int(o['bland']), repr(o['lower_bound'] + r))\n"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"),
+               os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")))
+    res = {}
+    for tag, env in (("on", {}), ("off", {"ORC_NO_PERT": "1"})):      # the switch is read once per process
+        out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split()
+        res[tag] = dict(status=out[0], obj=float(out[1]), pivots=int(out[2]), bland=int(out[3]), lb=float(out[4]))
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "solve_cfg4_bench.npz"))["obj"][1907]
+    for tag in ("on", "off"):
+        assert res[tag]["obj"] >= gold - 1e-6 * abs(gold) and res[tag]["lb"] <= gold + 1e-6 * abs(gold), (tag, res[tag], gold)
+        if res[tag]["status"] == "optimal":
+            assert res[tag]["obj"] - gold <= 1e-2 * abs(res[tag]["obj"]) + 1e-9
+    assert res["off"]["bland"] > 1000 and res["on"]["bland"] < 0.2 * res["off"]["bland"], res
+    assert res["on"]["pivots"] < 0.6 * res["off"]["pivots"], res
+
+
+def test_round3_fixtures_are_consistent():
+    """the committed HiGHS optima of bench.py's timed scenario set and of the steady-state closed-loop inputs: proven, bracketed, and
+    the oracle -- a different algorithm -- agrees on a sample at the bench's options"""
+    import os
+    import bench
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    timed = np.load(os.path.join(gdir, "solve_cfg4_timed.npz"))
+    cl = np.load(os.path.join(gdir, "solve_cfg4_closed_loop.npz"))
+    z = np.load(os.path.join(gdir, "closed_loop_cfg4_inputs.npz"))
+    assert timed["obj"].size == 1024 and np.all(timed["proven"] == 1) and np.all(timed["dual_bound"] <= timed["obj"] + 1e-6 * np.abs(timed["obj"]) + 1e-9)
+    assert cl["obj"].size == z["x0"].shape[0] == 256 and cl["proven"].mean() >= 0.95
+    assert z["x0"].min() > 45.0 and z["x0"].mean() < 58.5, "steady state sits near the lower temperature bound, below the seeded 55..64"
+    agents, N_p, N_t, _, _, _ = bench.make_shard(64, 1, 0)
+    xs, ws = bench.step_scenarios(0, 1, 64 * 512)
+    forms = {}
+    for kind, idx in (("timed", (0, 65, 130, 1023)), ("cl", (3, 100, 255))):
+        for i in idx:
+            a = int(i % 64) if kind == "timed" else int(z["model_idx"][i])
+            if a not in forms:
+                d = agents[a]["dims"]
+                forms[a] = cn.standard_form(tighten_np.tighten(agents[a]["mats"], d, nu_l=d["nu_l"]), agents[a]["atoms"], N_p, N_t, nu_l=d["nu_l"])
+            sf = forms[a]
+            x0, om = (xs[i], ws[i]) if kind == "timed" else (z["x0"][i], z["omega"][i])
+            h, q = cn.rhs(sf["evo"], x0, om), cn.lin_cost(sf["cost"], x0, om)
+            rc = cn.cost_const(sf["cost"]["const_terms"], x0, om)
+            r = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], gap_rel=1e-2, max_nodes=800, presolve=0, max_pivots=40000)
+            opt = (timed if kind == "timed" else cl)["obj"][i]
+            assert r["obj"] + rc >= opt - 1e-6 * abs(opt) and r["lower_bound"] + rc <= opt + 1e-6 * abs(opt), (kind, i)
+            if r["status"] == "optimal":
+                assert r["obj"] + rc - opt <= 1e-2 * abs(r["obj"] + rc) + 1e-9, (kind, i)

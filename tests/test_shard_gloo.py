@@ -97,3 +97,72 @@ def test_tcp_rendezvous_world3_without_torch():
         assert uid == bytes(range(128))
         assert slowest == 10.0 + world - 1
         assert np.array_equal(full, np.stack([idx, idx ** 2], axis=1))
+
+
+class _StubProblem(object):
+    """stands in for a GpuProblem handle: launch / finish take a rank- and handle-dependent time, calls are logged"""
+
+    def __init__(self, rank, hid, log):
+        self.rank, self.hid, self.log, self.step, self.set = rank, hid, log, -1, -1
+
+    def select(self, k):
+        self.set = k
+        self.log.append(("select", self.hid, k))
+
+    def launch(self):
+        self.step += 1
+        self.log.append(("launch", self.hid, self.set))
+
+    def finish(self):
+        import time
+        time.sleep(0.002 * ((self.rank * 7 + self.hid * 3 + self.step) % 5))     # ranks and handles finish at different speeds
+        self.log.append(("finish", self.hid, self.set))
+        return dict(n_optimal=1, set=self.set)
+
+
+class _StubGather(object):
+    """the result gather as a tagged collective over the rendezvous: every rank must arrive with the same (handle, scenario set)"""
+
+    def __init__(self, rd, log):
+        self.rd, self.log = rd, log
+
+    def gather_results(self, prob):
+        tag = ("%d:%d" % (prob.hid, prob.set)).encode()
+        got = self.rd.all_gather_bytes(tag)
+        self.log.append(("gather", prob.hid, prob.set, tuple(got)))
+        assert all(g == tag for g in got), (tag, got)
+
+
+def _pipeline_worker(rank, world, port, q):
+    import bench
+    from pyhybridcontrol_amd.batch import TcpRendezvous
+    rd = TcpRendezvous(rank=rank, world=world, addr="127.0.0.1", port=port, timeout=60.0)
+    log = []
+    probs = [_StubProblem(rank, h, log) for h in range(2)]
+    state = dict(k=0)
+    res = bench.run_pipelined(probs, 7, state, 5, _StubGather(rd, log))
+    rd.barrier()
+    rd.close()
+    q.put((rank, [r["set"] for r in res], [e[:3] for e in log]))
+
+
+def test_two_ranks_two_handles_issue_the_same_collective_sequence():
+    """bench.py's pipelined timed region (launch / finish / gather alternating over two handles) must issue its
+    collectives in the same order on every rank whatever the ranks' solve times, or the first 8-GPU run deadlocks in RCCL"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r, (sets, log)) for r, sets, log in (q.get(timeout=120) for _ in range(2)))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0] == [k % 5 for k in range(7)], "step j solves scenario set j, in order"
+    assert res[0][1] == res[1][1], "both ranks walk the same sequence of selects, launches, finishes and gathers"
+    kinds = [e[0] for e in res[0][1]]
+    assert kinds.count("gather") == 7 and kinds.count("launch") == 7 and kinds.count("finish") == 7
+    first_gather = kinds.index("gather")
+    assert kinds[:first_gather].count("launch") == 2, "two solves are in flight before the first finish: the steps overlap"
