@@ -1560,20 +1560,21 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
                     /* no backtracking: the dive ends at its first leaf, or when the node is infeasible */
                     if (branch_j < 0) dive_end = 1;
                     else {
-                        set_bounds(t, branch_j, 1.0, 1.0);
+                        const double tgt = 1.0;
+                        set_bounds(t, branch_j, tgt, tgt);
                         nodes++;
                         int la = dual_simplex(t, INFINITY);
                         const double oa = la == LP_OPTIMAL ? objective(t) : INFINITY;
-                        double take = 1.0;
+                        double take = tgt;
                         if (la == LP_ITERLIMIT) limit = 1;
                         else if (!(oa <= node_obj + dive_tol)) {
-                            set_bounds(t, branch_j, 0.0, 0.0);
+                            set_bounds(t, branch_j, 1.0 - tgt, 1.0 - tgt);
                             nodes++;
                             const int lb2 = dual_simplex(t, INFINITY);
                             const double ob2 = lb2 == LP_OPTIMAL ? objective(t) : INFINITY;
                             if (lb2 == LP_ITERLIMIT) limit = 1;
-                            else if (ob2 <= oa) { take = 0.0; if (ob2 == INFINITY) dive_end = 1; }
-                            else set_bounds(t, branch_j, 1.0, 1.0);
+                            else if (ob2 <= oa) { take = 1.0 - tgt; if (ob2 == INFINITY) dive_end = 1; }
+                            else set_bounds(t, branch_j, tgt, tgt);
                         }
                         (void)take;
                         stk_j[depth] = branch_j; stk_first[depth] = take; stk_second[depth] = 1; depth++;

@@ -131,8 +131,7 @@ def test_controller_scenario_and_minmax_blocks():
     assert abs(ctrl.solve(0, x_k=[50.3], omega_tilde_k=om) - 1.5) < 1e-9
     with pytest.raises(TypeError):
         ctrl.set_constraints(other_constraints=[object()])
-    with pytest.raises(NotImplementedError):
-        ctrl.set_constraints(other_constraints=[ctrl.gen_evo_constraints(x_k=[51.0])])
+    ctrl.set_constraints(other_constraints=[ctrl.gen_evo_constraints(x_k=[51.0])])     # explicit x_k blocks are accepted since round 3 (tests/test_gpu_round3.py)
 
 
 def test_controller_l1_atoms_through_epigraph_augmentation():
