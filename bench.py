@@ -85,6 +85,12 @@ def make_shard(n_agents, n_scen, scen_offset):
     return agents, N_p, N_t, x0.reshape(-1, nx), om.reshape(-1, nW), midx
 
 
+def progress(msg):
+    """one line on stderr (rank 0): a bench run prints its single JSON line at the very end, and a silent command is taken to be hung"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
+
+
 def step_scenarios(rank, t, n_local):
     """scenario set t >= 1 of a rank's timed region: (x0, omega) of its n_local instances, instance i on agent i % n_agents like set 0.
     Seeded by (cfg4 seed, 7919, rank, t) -- tests/golden/solve_cfg4_timed.npz pins the first instances of (rank 0, t = 1)."""
@@ -107,7 +113,21 @@ def host_description():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
-    return dict(cpu_model=model, nproc=os.cpu_count() or 1, usable_cores=usable)
+    quota = None
+    try:        # the container's CPU share (cgroup v2 cpu.max / v1 cfs quota): a one-GPU box grants a fraction of the host's hardware threads
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt[0] != "max":
+            quota = float(txt[0]) / float(txt[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        usable = max(1, min(usable, int(round(quota))))
+    return dict(cpu_model=model, nproc=os.cpu_count() or 1, usable_cores=usable, cpu_quota=quota)
 
 
 def cpu_baseline(agents, N_p, N_t, x0, om, midx, n_sample, gap, node_limit, pivot_limit):
@@ -137,19 +157,7 @@ def cpu_baseline(agents, N_p, N_t, x0, om, midx, n_sample, gap, node_limit, pivo
         hs.append(cn.rhs(sf["evo"], x0[i], om[i]))
         Gs.append(sf["G"])
     sf0 = forms[int(midx[idx[0]])]
-    opts = dict(gap_rel=gap, max_nodes=node_limit, presolve=0, max_pivots=pivot_limit)
-    n1 = min(32, len(idx))
-    t0 = time.perf_counter()
-    r1, _ = orc.solve_milp_batch(qs[:n1], Gs[:n1], hs[:n1], sf0["lb"], sf0["ub"], sf0["is_bin"], threads=1, **opts)
-    t1 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    ra, used = orc.solve_milp_batch(qs, Gs, hs, sf0["lb"], sf0["ub"], sf0["is_bin"], threads=host["usable_cores"], **opts)
-    ta = time.perf_counter() - t0
-    out = dict(value=round(len(idx) / ta, 3), unit="agent-solves/s", cores=int(used), kind="port",
-               value_all=round(len(idx) / ta, 3), value_1t=round(n1 / t1, 3), nproc=host["nproc"], cpu_model=host["cpu_model"],
-               sample="%d instances spread over the rank-0 shard (all %d agents, scenarios 0..%d), same MIPGap/NodeLimit/IterationLimit, "
-                      "oracle/mld_oracle.c with OpenMP over instances on %d threads (%d proven, %d node-limited); value_1t: the first %d of them on one thread"
-                      % (len(idx), len(forms), x0.shape[0] // len(agents) - 1, used, int((ra["status"] == 0).sum()), int((ra["status"] == 2).sum()), n1))
+    # (first: the pool forks its workers, and a fork after the OpenMP region of the oracle below is not safe with libgomp)
     # an independent third-party CPU solver on the SAME sample (original, un-tightened rows): scipy's HiGHS at the same MIPGap, one process per
     # core (the instances are independent -- SURVEY 8d "as an independent third-party CPU reference"), and the one-thread rate beside it
     try:
@@ -159,26 +167,53 @@ def cpu_baseline(agents, N_p, N_t, x0, om, midx, n_sample, gap, node_limit, pivo
             if a not in raw:
                 raw[a] = cn.standard_form(agents[a]["mats"], agents[a]["atoms"], N_p, N_t, nu_l=agents[a]["dims"]["nu_l"])
         _HIGHS.update(raw=raw, x0=x0, om=om, midx=midx, gap=gap)
+        progress("cpu baseline: HiGHS on %d instances, 1 thread then a fork pool" % len(idx))
+        procs = max(1, min(host["usable_cores"], len(idx)))
+        t0 = time.perf_counter()
+        # fork, never spawn / exec: nothing in this process has touched the GPU yet (main() runs this leg first) -- and the parent has not run
+        # HiGHS yet either (its global task executor owns threads that a forked child would wait for in vain)
+        with mp.get_context("fork").Pool(procs, initializer=_highs_init) as pool:
+            res = pool.map_async(_highs_one, [int(i) for i in idx], chunksize=max(1, len(idx) // (4 * procs))).get(timeout=240)      # (a stuck pool must not stall the bench)
+        t_all = time.perf_counter() - t0
         t0 = time.perf_counter()
         one = [_highs_one(int(i)) for i in idx[:8]]
         t_1 = time.perf_counter() - t0
-        procs = max(1, min(host["usable_cores"], len(idx)))
-        t0 = time.perf_counter()
-        with mp.get_context("fork").Pool(procs) as pool:       # fork, never spawn / exec: nothing in this process has touched the GPU yet (main() runs this leg first)
-            res = pool.map(_highs_one, [int(i) for i in idx], chunksize=max(1, len(idx) // (4 * procs)))
-        t_all = time.perf_counter() - t0
-        out["third_party"] = dict(solver="scipy.optimize.milp (HiGHS), mip_rel_gap=%g, original rows" % gap, value_all=round(len(idx) / t_all, 3),
+        third = dict(solver="scipy.optimize.milp (HiGHS), mip_rel_gap=%g, original rows" % gap, value_all=round(len(idx) / t_all, 3),
                                   cores=procs, value=round(len(one) / t_1, 3), unit="agent-solves/s", solved=int(sum(r[0] for r in res)),
                                   cpu_seconds_per_instance=round(float(np.mean([r[1] for r in res])), 4),
                                   sample="value_all: the same %d instances, one process per core (%d processes, multiprocessing fork pool, wall clock "
                                          "incl. pool start-up); value: the first %d of them on one thread" % (len(idx), procs, len(one)))
     except Exception as e:      # noqa: BLE001 -- reported, not fatal: the baseline above stands on its own
-        out["third_party"] = dict(solver="scipy.optimize.milp (HiGHS)", error=str(e)[:200])
+        third = dict(solver="scipy.optimize.milp (HiGHS)", error=str(e)[:200])
+    opts = dict(gap_rel=gap, max_nodes=node_limit, presolve=0, max_pivots=pivot_limit)
+    n1 = min(32, len(idx))
+    progress("cpu baseline: the C oracle on %d instances (1 thread, then OpenMP on %d threads)" % (len(idx), host["usable_cores"]))
+    t0 = time.perf_counter()
+    r1, _ = orc.solve_milp_batch(qs[:n1], Gs[:n1], hs[:n1], sf0["lb"], sf0["ub"], sf0["is_bin"], threads=1, **opts)
+    t1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ra, used = orc.solve_milp_batch(qs, Gs, hs, sf0["lb"], sf0["ub"], sf0["is_bin"], threads=host["usable_cores"], **opts)
+    ta = time.perf_counter() - t0
+    out = dict(value=round(len(idx) / ta, 3), unit="agent-solves/s", cores=int(used), kind="port",
+               value_all=round(len(idx) / ta, 3), value_1t=round(n1 / t1, 3), nproc=host["nproc"], cpu_quota=host["cpu_quota"], cpu_model=host["cpu_model"],
+               sample="%d instances spread over the rank-0 shard (all %d agents, scenarios 0..%d), same MIPGap/NodeLimit/IterationLimit, "
+                      "oracle/mld_oracle.c with OpenMP over instances on %d threads (%d proven, %d node-limited); value_1t: the first %d of them on one thread"
+                      % (len(idx), len(forms), x0.shape[0] // len(agents) - 1, used, int((ra["status"] == 0).sum()), int((ra["status"] == 2).sum()), n1))
+    out["third_party"] = third
     out["note"] = "Gurobi at MIPGap=1e-2 (the reference's backend) is not installable here and was not measured"
     return out
 
 
 _HIGHS = {}
+
+
+def _highs_init():
+    """pool worker: one thread per process (numpy's BLAS pool would otherwise start a thread per hardware thread in every worker)"""
+    try:
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(1)
+    except Exception:       # noqa: BLE001
+        pass
 
 
 def _highs_one(i):
@@ -280,7 +315,9 @@ def main():
     n_local = x0.shape[0]
     exact = None
     if world == 1 and args.exact_sample != 0:
+        progress("exact-gap leg (1e-6) on the shard")
         exact = exact_leg(prob, x0, om, midx, args.exact_sample, args)
+    progress("staging %d scenario sets" % (args.warmup + args.steps + max(1, args.reference_steps) + 2))
     prob.upload(x0, om, midx)                       # inputs resident in HBM before the timed region
     # fresh scenario sets for every step (set 0 = the shard's own scenarios), all resident in HBM before the timed region
     from pyhybridcontrol_amd import synthetic as syn
@@ -339,6 +376,7 @@ def main():
             return [step() for _ in range(count)]
         return run_pipelined(probs, count, state, n_sets, gatherer)
 
+    progress("warm-up (%d) and timed steps (%d)" % (args.warmup, args.steps))
     run_steps(args.warmup)
     sync()
     t0 = time.perf_counter()
@@ -467,6 +505,7 @@ def main():
     if args.closed_loop_steps > 0:
         # closed loop: the SAME scenarios advanced step by step (plant update with the inputs just computed, forecast shifted)
         rates, prov = [], []
+        progress("closed loop: %d steps" % args.closed_loop_steps)
         for _ in range(args.closed_loop_steps):
             sync()
             t0 = time.perf_counter()
