@@ -70,7 +70,7 @@ typedef struct {
     int32_t presolve;      /* bit1: per-model probing-based big-M tightening (default 2); bit0 reserved */
     int32_t n_slots;       /* solver slots = persistent workgroups (0 = auto: what is resident at once, one per CU) */
     int32_t mir_per_round; /* complemented mixed-integer rounding cuts on the original rows per cut round
-                              (default -1 = max(10, binaries / 20); 0 = off) */
+                              (default -1 = max(20, binaries / 10); 0 = off) */
     int32_t flags;         /* MLD_F32 (default 0, see below) */
     int32_t reserved;      /* diagnostics, default 0.  bit0 solver trace (builds with -DMLD_TRACE only), bit1 refactor at every
                               verification, bit2 never refactor, bit3 no longest-first work queue, bit4 keep maintaining the rows

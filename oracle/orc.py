@@ -57,7 +57,7 @@ def _p(a):
 
 
 def make_opts(gap_abs=1e-9, gap_rel=0.0, max_nodes=100000, cut_rounds=10, cuts_per_round=80, max_cuts=300,
-              max_pivots=0, presolve=1, mir_per_round=10):
+              max_pivots=0, presolve=1, mir_per_round=20):
     return Opts(gap_abs, gap_rel, max_nodes, cut_rounds, cuts_per_round, max_cuts, max_pivots, presolve, mir_per_round)
 
 
