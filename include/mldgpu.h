@@ -64,13 +64,13 @@ typedef struct {
     double gap_rel;        /* relative MIP gap (Gurobi MIPGap; default 0 = prove optimality) */
     int32_t max_nodes;     /* per instance (default 100000) */
     int32_t max_pivots;    /* per instance simplex iteration limit (default 50000) */
-    int32_t cut_rounds;    /* Gomory mixed-integer cut rounds at the root (default 10) */
+    int32_t cut_rounds;    /* cut rounds at the root (default -1 = max(10, min(30, binaries / 40)); 0 = no cuts) */
     int32_t cuts_per_round;/* Gomory cuts per round (default -1 = max(80, binaries / 5)) */
-    int32_t max_cuts;      /* rows reserved for cuts (default -1 = max(300, rows / 4); 0 = no cuts) */
+    int32_t max_cuts;      /* rows reserved for cuts (default -1 = max(300, rows / 4) up to 400 binaries, rows / 2 above; 0 = no cuts) */
     int32_t presolve;      /* bit1: per-model probing-based big-M tightening (default 2); bit0 reserved */
     int32_t n_slots;       /* solver slots = persistent workgroups (0 = auto: what is resident at once, one per CU) */
     int32_t mir_per_round; /* complemented mixed-integer rounding cuts on the original rows per cut round
-                              (default -1 = max(20, binaries / 10); 0 = off) */
+                              (default -1 = 20 up to 400 binaries, binaries / 5 above; 0 = off) */
     int32_t flags;         /* MLD_F32 (default 0, see below) */
     int32_t reserved;      /* diagnostics, default 0.  bit0 solver trace (builds with -DMLD_TRACE only), bit1 refactor at every
                               verification, bit2 never refactor, bit3 no longest-first work queue, bit4 keep maintaining the rows

@@ -1359,14 +1359,6 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
         st->phase_work[0] = t->work;
         root_ok = 1;
         st->cuts = 0;
-        if (x_start && !started && getenv("ORC_WARM_EAGER")) {
-            /* (study variant: the start evaluated before the cut loop)  MIP start: the start's binaries as a leaf -- the initial incumbent when it satisfies the original rows -- then back to the root optimum */
-            started = 1;
-            leaf_eval(t, &L, x_start);
-            st->nodes++;
-            lp = dual_simplex(t, INFINITY);
-            if (lp != LP_OPTIMAL) { root_ok = 0; continue; }
-        }
         if (use_cuts) {
             int stalled = 0;
             const long saved_cap = t->max_pivots;
@@ -1424,7 +1416,7 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
         enum { PH_IDS = 0, PH_DIVE, PH_RINS, PH_FINAL };
         const double root_bound = st->root_bound;
         int nodes = 0, limit = 0, pass = 0, rescue = 0, node_budget = o->max_nodes;
-        int phase = started && have ? PH_FINAL : PH_IDS, rins_rounds = 0, nfix = 0;     /* with a MIP start: guided search towards it from the first node */
+        int phase = PH_IDS, rins_rounds = 0, nfix = 0;
         int ids_cap = o->max_nodes / 8 > 16 ? o->max_nodes / 8 : 16;
         if (getenv("ORC_IDS_CAP")) { const int c = atoi(getenv("ORC_IDS_CAP")); if (c < ids_cap) ids_cap = c; }
         const double dive_tol = 1e-2 * fmax(1.0, fabs(root_bound));
