@@ -56,6 +56,7 @@ def parse():
                     "the workgroups of step k+1 move onto the CUs the stragglers of step k leave idle; 1 = one step after another")
     ap.add_argument("--reference-steps", type=int, default=2, help="steps solved strictly one after another after the timed region (roofline, latency, value_one_at_a_time)")
     ap.add_argument("--reserved", type=int, default=0, help="diagnostics: opts.reserved bits for the solver (include/mldgpu.h), e.g. 1024 = the experimental LDS-resident branch-and-cut")
+    ap.add_argument("--solver-opts", type=str, default="", help="diagnostics: extra solver options as python kwargs, e.g. 'mir_per_round=10'")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank rehearsal on ONE GPU: every rank on device 0, gather over the TCP side channel")
     return ap.parse_args()
 
@@ -325,7 +326,7 @@ def main():
     d = agents[0]["dims"]
     model = gpu.GpuModel([a["mats"] for a in agents], d)
     cost = host.stack_costs([host.cost_from_atoms(a["atoms"], d, N_p, N_t) for a in agents])
-    prob = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit, reserved=args.reserved)
+    prob = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit, reserved=args.reserved, **eval("dict(%s)" % args.solver_opts))
     n_local = x0.shape[0]
     exact = None
     if world == 1 and args.exact_sample != 0:
@@ -346,7 +347,7 @@ def main():
     H = max(1, args.handles)
     probs = [prob]
     for _ in range(1, H):
-        q = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit, reserved=args.reserved)
+        q = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit, reserved=args.reserved, **eval("dict(%s)" % args.solver_opts))
         q.upload(x0, om, midx); q.stage(x0_sets, om_sets)
         probs.append(q)
     if H > 1:

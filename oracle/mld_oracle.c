@@ -566,7 +566,7 @@ static int dual_simplex_impl(dict_t *t, double cutoff)
     double last_obj = -INFINITY;
     static int pert_env = -1;
     if (pert_env < 0) pert_env = getenv("ORC_NO_PERT") ? 0 : 1;
-    int pert_ok = pert_env && cutoff == INFINITY && !t->P;      /* one perturbation per solve, only where no cutoff reads the (perturbed) objective */
+    int pert_ok = pert_env && !t->P;      /* one perturbation per solve; while the cost row is perturbed the objective cutoff is suspended (the caller compares the true value) */
     const double *d = t->D + (size_t)t->mcap * ld;
     long checked_at = t->pivots;     /* pivot count at the last verification against the original rows */
     for (;;) {
@@ -598,7 +598,7 @@ static int dual_simplex_impl(dict_t *t, double cutoff)
             return unperturb(t, LP_OPTIMAL);
         }
         if (bland) r = rb;
-        if (cur >= cutoff) {
+        if (cur >= cutoff && !t->perturbed) {
             /* a cutoff is a claim about the bound: verify the dictionary first if it has moved since the last check */
             if (t->pivots - checked_at >= 64) {
                 checked_at = t->pivots;
