@@ -270,6 +270,15 @@ def exact_leg(prob, x0, om, midx, n_exact, args):
         res["worst_rel_diff_proven"] = float(np.abs(rel[pk]).max()) if pk.any() else None
         res["worst_rel_above_optimum_all"] = float(rel[np.isfinite(rel)].max())
         res["below_optimum"] = int((rel < -1e-6).sum())
+    # the same leg with the per-instance work capped at a quarter (IterationLimit 100 000): the leg above is latency-bound by its slowest instance
+    # (slowest_instance_ms: one instance running to the 400 000-pivot cap holds the whole launch while the other CUs idle -- value_no_idle_bound)
+    prob.set_opts(gap_rel=1e-6, max_nodes=20000, max_pivots=100000)
+    t0 = time.perf_counter()
+    st2 = prob.solve_resident()
+    wall2 = time.perf_counter() - t0
+    out2 = prob.download()
+    res["capped"] = dict(iteration_limit=100000, value_exact=round(n_exact / wall2, 2), ms=round(wall2 * 1e3, 2), kernel_ms=round(st2["solve_ms"], 2),
+                         proven_fraction=round(float((out2["status"] == 0).mean()), 5), pivots_per_instance=round(float(out2["pivots"].mean()), 1))
     prob.set_opts(gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit)
     return res
 
