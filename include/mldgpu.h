@@ -244,6 +244,21 @@ int mld_set_warm_start(mld_problem_t *, const uint8_t *bin_start);
  * to the reference's backend: the variables' previous values), shift = k > 0 moves it k steps towards the present and repeats its last step
  * (receding horizon: call after mld_advance_batch).  Instances without an incumbent get no start. */
 int mld_warm_start_from_previous(mld_problem_t *, int shift);
+
+/* ---- sub-tree hand-off: open nodes of a stopped search become instances of the next batch -------------------------------------
+ * The reference's backend runs one branch-and-bound per solve() call to its gap (controllers/controller_base.py:509; TimeLimit 20 s in
+ * the example); here a batch gives every instance ONE workgroup, so a few instances with large trees hold a launch while the other CUs
+ * idle.  With recording enabled, an instance that stops at a limit inside a complete search (plain depth-first search below its
+ * incumbent) returns its stack: depth, and per level the variable (index into the decision vector), its current value and a flag
+ * "sibling accounted for".  Everything still open is then: for each level k with flag 0 the node {levels < k at their values, level k
+ * flipped}, plus the node {all levels at their values}.  The caller uploads those nodes as instances of a new batch (same x0 / omega,
+ * the node's fixings in fixed_bin, everything else 255) with the parent's incumbent value as cutoff: every CU works on the tail.
+ * mld_set_cutoffs: per instance of the resident batch the objective (constant term included) that must be beaten; +inf = none, NULL
+ * clears.  Under a cutoff a search that finds nothing better ends INFEASIBLE with objective +inf ("nothing better exists in this node").
+ * pyhybridcontrol_amd.gpu.GpuProblem.solve_handoff drives the rounds and merges the results. */
+int mld_set_cutoffs(mld_problem_t *, const double *cutoff);
+int mld_record_open_nodes(mld_problem_t *, int enable);
+int mld_download_open_nodes(mld_problem_t *, int32_t *depth_out, int16_t *var_out, uint8_t *val_out, uint8_t *flag_out);
 /* Scenario streaming with everything resident in HBM: the parameter update at the top of the reference's solve() (x_k and
  * omega_tilde set as cvx.Parameter values, controllers/controller_base.py:495-498; the example re-solves with new forecasts every
  * step, micro_grid_control_simulation.py:229-232) for a whole batch.  mld_stage_inputs uploads n_sets input sets of the uploaded

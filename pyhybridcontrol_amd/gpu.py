@@ -327,6 +327,117 @@ class GpuProblem(object):
         out["stats"] = stats
         return out
 
+    # -- sub-tree hand-off ---------------------------------------------------------------------------
+    def set_cutoffs(self, cutoff):
+        """objective (constant term included) every instance of the resident batch has to beat (mld_set_cutoffs); inf = none, None clears"""
+        if cutoff is None:
+            check(_lib.load().mld_set_cutoffs(self._h, None))
+            return
+        c = _lib.as_f64(cutoff).reshape(self.batch)
+        check(_lib.load().mld_set_cutoffs(self._h, _lib.dptr(c)))
+
+    def record_open_nodes(self, enable=True):
+        check(_lib.load().mld_record_open_nodes(self._h, 1 if enable else 0))
+
+    def open_nodes(self):
+        """search stacks of the instances that stopped at a limit inside a complete search (mld_download_open_nodes):
+        depth (batch; -1 = none), var / val / flag (batch, n_bin)"""
+        b, nb = self.batch, max(1, self.n_bin)
+        depth = np.zeros(b, np.int32)
+        var, val, flag = np.zeros((b, nb), np.int16), np.zeros((b, nb), np.uint8), np.zeros((b, nb), np.uint8)
+        check(_lib.load().mld_download_open_nodes(self._h, depth.ctypes.data_as(C.POINTER(C.c_int32)), var.ctypes.data_as(C.POINTER(C.c_int16)),
+                                                  val.ctypes.data_as(C.POINTER(C.c_uint8)), flag.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return depth, var, val, flag
+
+    def solve_handoff(self, x0, omega, model_idx=None, fixed_bin=None, rounds=3, first_nodes=None, sub_nodes=None, max_sub=None):
+        """The batch solved with sub-tree hand-off: a first pass over all instances (node limit `first_nodes`, default the problem's), then up to
+        `rounds` passes in which the OPEN NODES of the instances that stopped at the limit -- read off their depth-first stacks -- are solved as
+        instances of their own (node limit `sub_nodes` each, the parent's incumbent value as cutoff), so the whole device works on the few large
+        trees instead of one workgroup per tree.  An instance is proven once every one of its nodes has been closed.  Returns the dict of
+        download() (v, obj, status, lower_bound; nodes / pivots summed over all passes) plus `handoff` statistics; the resident batch afterwards
+        is the last pass's sub-batch (upload again before advance() / warm starts)."""
+        d = self.model.dims
+        x0 = _lib.as_f64(x0).reshape(-1, d["nx"]) if d["nx"] else np.zeros((np.shape(omega)[0], 0))
+        B = x0.shape[0] if d["nx"] else int(np.asarray(omega).reshape(-1, max(self.nW, 1)).shape[0])
+        omega = _lib.as_f64(omega).reshape(B, self.nW) if self.nW else np.zeros((B, 0))
+        mi = np.ascontiguousarray(model_idx, dtype=np.int32) if model_idx is not None else None
+        nb = self.n_bin
+        base = np.full((B, nb), 255, np.uint8) if fixed_bin is None else np.ascontiguousarray(fixed_bin, dtype=np.uint8).reshape(B, nb).copy()
+        pos = np.full(self.n, -1, np.int64)
+        pos[np.flatnonzero(self.is_bin)] = np.arange(nb)
+        keep_nodes = int(self.opts.max_nodes)
+        gap_rel, gap_abs = float(self.opts.gap_rel), float(self.opts.gap_abs)
+        self.record_open_nodes(True)
+        try:
+            if first_nodes is not None:
+                self.set_opts(max_nodes=int(first_nodes))
+            out = self.solve(x0, omega, mi, None if fixed_bin is None else base)
+            depth, var, val, flag = self.open_nodes()
+            obj, v, status, lb = out["obj"].copy(), out["v"].copy(), out["status"].copy(), out["lower_bound"].copy()
+            nodes, pivots = out["nodes"].astype(np.int64), out["pivots"].astype(np.int64)
+            stats = dict(first_pass_ms=out["stats"]["solve_ms"], rounds=[], handed_off=0)
+
+            def expand(fix, dep, vr, vl, fl):
+                res, path = [], fix.copy()
+                for k in range(int(dep)):
+                    kp = pos[int(vr[k])]
+                    if not fl[k]:
+                        f = path.copy(); f[kp] = 1 - vl[k]; res.append(f)
+                    path[kp] = vl[k]
+                res.append(path)
+                return res
+
+            open_list = {}      # parent -> list of (fixings, lower bound valid for that node)
+            for i in np.flatnonzero((status == 2) & (depth >= 0)):
+                open_list[int(i)] = [(f, lb[i]) for f in expand(base[i], depth[i], var[i], val[i], flag[i])]
+            stats["handed_off"] = len(open_list)
+            if sub_nodes is not None:
+                self.set_opts(max_nodes=int(sub_nodes))
+            for r in range(int(rounds)):
+                if not open_list:
+                    break
+                par = np.array([i for i, lst in open_list.items() for _ in lst], dtype=np.int64)
+                fix = np.stack([f for lst in open_list.values() for f, _ in lst])
+                nlb = np.array([b_ for lst in open_list.values() for _, b_ in lst])
+                if max_sub is not None and par.size > max_sub:
+                    break
+                self.upload(x0[par], omega[par], mi[par] if mi is not None else None, fix)
+                self.set_cutoffs(obj[par])
+                st = self.solve_resident()
+                sub = self.download()
+                d2, v2, l2, f2 = self.open_nodes()
+                stats["rounds"].append(dict(sub_instances=int(par.size), parents=len(open_list), ms=st["solve_ms"]))
+                new_open, stuck = {}, set()
+                for s_ in range(par.size):
+                    i = int(par[s_])
+                    nodes[i] += sub["nodes"][s_]; pivots[i] += sub["pivots"][s_]
+                    if np.isfinite(sub["obj"][s_]) and sub["obj"][s_] < obj[i]:
+                        obj[i], v[i] = sub["obj"][s_], sub["v"][s_]
+                    ss = int(sub["status"][s_])
+                    if ss in (0, 1):
+                        continue                                    # closed: optimum of the node found, or nothing better than the cutoff in it
+                    if ss == 2 and d2[s_] >= 0:
+                        new_open.setdefault(i, []).extend((f, max(nlb[s_], sub["lower_bound"][s_])) for f in expand(fix[s_], d2[s_], v2[s_], l2[s_], f2[s_]))
+                    else:
+                        stuck.add(i)                                # a node that cannot be split further (numerical trouble, incomplete phase): stays open
+                        new_open.setdefault(i, []).append((fix[s_], max(nlb[s_], sub["lower_bound"][s_]) if np.isfinite(sub["lower_bound"][s_]) else nlb[s_]))
+                for i in list(open_list):
+                    tol = max(gap_abs, gap_rel * abs(obj[i])) if np.isfinite(obj[i]) else 0.0
+                    if i not in new_open:                           # every node closed: proven
+                        status[i] = 0 if np.isfinite(obj[i]) else 1
+                        lb[i] = min(obj[i], max(lb[i], obj[i] - tol)) if np.isfinite(obj[i]) else lb[i]
+                    else:
+                        lb[i] = max(lb[i], min(min(b_ for _, b_ in new_open[i]), obj[i] - tol if np.isfinite(obj[i]) else np.inf))
+                open_list = {i: lst for i, lst in new_open.items()}
+                if stuck and all(i in stuck for i in open_list) and r + 1 < rounds:
+                    pass                                            # (stuck nodes are simply retried with the next round's budget)
+            stats["unfinished"] = len(open_list)
+            return dict(v=v, obj=obj, status=status, lower_bound=lb, nodes=nodes, pivots=pivots, stats=out["stats"], handoff=stats)
+        finally:
+            self.record_open_nodes(False)
+            self.set_opts(max_nodes=keep_nodes)
+            self.set_cutoffs(None)
+
     def rhs(self, x0, omega, model_idx=None, scenarios=1):
         """h = H_x x_k + H_omega omega + H_5 (row-min over `scenarios` omega columns), original model"""
         d = self.model.dims
