@@ -388,8 +388,10 @@ class GpuProblem(object):
                 return res
 
             open_list = {}      # parent -> list of (fixings, lower bound valid for that node)
-            for i in np.flatnonzero((status == 2) & (depth >= 0)):
-                open_list[int(i)] = [(f, lb[i]) for f in expand(base[i], depth[i], var[i], val[i], flag[i])]
+            for i in np.flatnonzero(status == 2):
+                # a search that stopped before it became a plain depth-first search below an incumbent (deepening passes, dive, RINS) has no
+                # stack that describes what is left: its one open node is the root, searched again under the incumbent's value as cutoff
+                open_list[int(i)] = [(f, lb[i]) for f in (expand(base[i], depth[i], var[i], val[i], flag[i]) if depth[i] >= 0 else [base[i].copy()])]
             stats["handed_off"] = len(open_list)
             if sub_nodes is not None:
                 self.set_opts(max_nodes=int(sub_nodes))
@@ -416,11 +418,12 @@ class GpuProblem(object):
                     ss = int(sub["status"][s_])
                     if ss in (0, 1):
                         continue                                    # closed: optimum of the node found, or nothing better than the cutoff in it
+                    nl = max(nlb[s_], sub["lower_bound"][s_]) if np.isfinite(sub["lower_bound"][s_]) else nlb[s_]
                     if ss == 2 and d2[s_] >= 0:
-                        new_open.setdefault(i, []).extend((f, max(nlb[s_], sub["lower_bound"][s_])) for f in expand(fix[s_], d2[s_], v2[s_], l2[s_], f2[s_]))
+                        new_open.setdefault(i, []).extend((f, nl) for f in expand(fix[s_], d2[s_], v2[s_], l2[s_], f2[s_]))
                     else:
-                        stuck.add(i)                                # a node that cannot be split further (numerical trouble, incomplete phase): stays open
-                        new_open.setdefault(i, []).append((fix[s_], max(nlb[s_], sub["lower_bound"][s_]) if np.isfinite(sub["lower_bound"][s_]) else nlb[s_]))
+                        stuck.add(i)                                # a node that could not be split (numerical trouble, no complete search yet): retried as it is
+                        new_open.setdefault(i, []).append((fix[s_], nl))
                 for i in list(open_list):
                     tol = max(gap_abs, gap_rel * abs(obj[i])) if np.isfinite(obj[i]) else 0.0
                     if i not in new_open:                           # every node closed: proven
