@@ -50,13 +50,14 @@ def test_cutoff_semantics():
 
 
 def test_handoff_with_a_tiny_first_pass_equals_the_unlimited_search():
-    """first pass of 3 nodes per instance: nearly every instance is handed off, several rounds deep; the merged result is the exact optimum"""
+    """first pass of 3 nodes per instance, 12 per open node afterwards: the instances that need a tree are handed off, several rounds deep; the merged
+    result is the exact optimum"""
     wl, ag, m, p = _cfg2(48, gap_rel=0.0, max_nodes=100000)
     ref = p.solve(ag["x0"], ag["omega"])
     assert np.all(ref["status"] == 0)
-    out = p.solve_handoff(ag["x0"], ag["omega"], first_nodes=3, sub_nodes=40, rounds=12)
+    out = p.solve_handoff(ag["x0"], ag["omega"], first_nodes=3, sub_nodes=12, rounds=30)
     print("handoff:", out["handoff"])
-    assert out["handoff"]["handed_off"] >= 8 and len(out["handoff"]["rounds"]) >= 2
+    assert out["handoff"]["handed_off"] >= 3 and len(out["handoff"]["rounds"]) >= 2
     assert np.all(out["status"] == 0), np.unique(out["status"], return_counts=True)
     assert np.allclose(out["obj"], ref["obj"], rtol=1e-9, atol=1e-9)
     assert np.all(out["lower_bound"] <= out["obj"] + 1e-9) and np.all(out["lower_bound"] >= ref["obj"] - 1e-6 * np.maximum(1.0, np.abs(ref["obj"])))
