@@ -217,6 +217,8 @@ int mld_download_results(mld_problem_t *, double *v_out, double *obj_out, int32_
  * per-call **solver_kwargs of solve() (controllers/controller_base.py:491-512): they must not need a rebuild.  max_cuts,
  * n_slots and presolve shape the workspace / the tightened model and are ignored here. */
 int mld_problem_set_opts(mld_problem_t *, const mld_opts *opts);
+/* the options in effect, every size-scaled default (-1 fields of mld_opts_default) resolved */
+int mld_problem_get_opts(mld_problem_t *, mld_opts *opts_out);
 
 /* Receding horizon on device -- the plant update the reference performs after every solve, ControllerBase.sim_step_k ->
  * MldModel.lsim_k (controllers/controller_base.py:229-253, models/mld_model.py:647-699): for every instance of the uploaded

@@ -143,6 +143,7 @@ class GpuProblem(object):
         c, keep = self._cost_struct(cost)
         check(_lib.load().mld_problem_create(C.byref(self._h), model._h, self.N_p, self.N_tilde,
                                              C.byref(c) if c is not None else None, C.byref(self.opts)))
+        check(_lib.load().mld_problem_get_opts(self._h, C.byref(self.opts)))      # the size-scaled defaults, resolved
         self.batch = 0
 
     def _cost_struct(self, cost):
@@ -349,7 +350,7 @@ class GpuProblem(object):
                                                   val.ctypes.data_as(C.POINTER(C.c_uint8)), flag.ctypes.data_as(C.POINTER(C.c_uint8))))
         return depth, var, val, flag
 
-    def solve_handoff(self, x0, omega, model_idx=None, fixed_bin=None, rounds=3, first_nodes=None, sub_nodes=None, max_sub=None):
+    def solve_handoff(self, x0, omega, model_idx=None, fixed_bin=None, rounds=3, first_nodes=None, sub_nodes=None, max_sub=None, sub_opts=None):
         """The batch solved with sub-tree hand-off: a first pass over all instances (node limit `first_nodes`, default the problem's), then up to
         `rounds` passes in which the OPEN NODES of the instances that stopped at the limit -- read off their depth-first stacks -- are solved as
         instances of their own (node limit `sub_nodes` each, the parent's incumbent value as cutoff), so the whole device works on the few large
@@ -395,6 +396,10 @@ class GpuProblem(object):
             stats["handed_off"] = len(open_list)
             if sub_nodes is not None:
                 self.set_opts(max_nodes=int(sub_nodes))
+            keep_sub = {}
+            if sub_opts:                                            # e.g. a shallower root cut loop for the open nodes
+                keep_sub = {k: getattr(self.opts, k) for k in sub_opts}
+                self.set_opts(**sub_opts)
             for r in range(int(rounds)):
                 if not open_list:
                     break
@@ -409,6 +414,7 @@ class GpuProblem(object):
                 sub = self.download()
                 d2, v2, l2, f2 = self.open_nodes()
                 stats["rounds"].append(dict(sub_instances=int(par.size), parents=len(open_list), ms=st["solve_ms"]))
+                rstat = stats["rounds"][-1]
                 new_open, stuck = {}, set()
                 for s_ in range(par.size):
                     i = int(par[s_])
@@ -432,6 +438,7 @@ class GpuProblem(object):
                     else:
                         lb[i] = max(lb[i], min(min(b_ for _, b_ in new_open[i]), obj[i] - tol if np.isfinite(obj[i]) else np.inf))
                 open_list = {i: lst for i, lst in new_open.items()}
+                rstat["parents_left"] = len(open_list)
                 if stuck and all(i in stuck for i in open_list) and r + 1 < rounds:
                     pass                                            # (stuck nodes are simply retried with the next round's budget)
             stats["unfinished"] = len(open_list)
@@ -439,6 +446,8 @@ class GpuProblem(object):
         finally:
             self.record_open_nodes(False)
             self.set_opts(max_nodes=keep_nodes)
+            if sub_opts and keep_sub:
+                self.set_opts(**keep_sub)
             self.set_cutoffs(None)
 
     def rhs(self, x0, omega, model_idx=None, scenarios=1):
