@@ -350,11 +350,13 @@ class GpuProblem(object):
                                                   val.ctypes.data_as(C.POINTER(C.c_uint8)), flag.ctypes.data_as(C.POINTER(C.c_uint8))))
         return depth, var, val, flag
 
-    def solve_handoff(self, x0, omega, model_idx=None, fixed_bin=None, rounds=3, first_nodes=None, sub_nodes=None, max_sub=None, sub_opts=None):
+    def solve_handoff(self, x0, omega, model_idx=None, fixed_bin=None, rounds=3, first_nodes=None, sub_nodes=None, max_sub=None, sub_opts=None,
+                      max_open=None):
         """The batch solved with sub-tree hand-off: a first pass over all instances (node limit `first_nodes`, default the problem's), then up to
         `rounds` passes in which the OPEN NODES of the instances that stopped at the limit -- read off their depth-first stacks -- are solved as
         instances of their own (node limit `sub_nodes` each, the parent's incumbent value as cutoff), so the whole device works on the few large
-        trees instead of one workgroup per tree.  An instance is proven once every one of its nodes has been closed.  Returns the dict of
+        trees instead of one workgroup per tree.  An instance is proven once every one of its nodes has been closed; one whose open nodes
+        outnumber `max_open` after a pass is given up (NODE_LIMIT with its incumbent and bound).  Returns the dict of
         download() (v, obj, status, lower_bound; nodes / pivots summed over all passes) plus `handoff` statistics; the resident batch afterwards
         is the last pass's sub-batch (upload again before advance() / warm starts)."""
         d = self.model.dims
@@ -438,10 +440,15 @@ class GpuProblem(object):
                     else:
                         lb[i] = max(lb[i], min(min(b_ for _, b_ in new_open[i]), obj[i] - tol if np.isfinite(obj[i]) else np.inf))
                 open_list = {i: lst for i, lst in new_open.items()}
+                if max_open is not None:                            # a tree that keeps growing is given up (it stays NODE_LIMIT with its incumbent and bound)
+                    gave_up = [i for i, lst in open_list.items() if len(lst) > max_open]
+                    for i in gave_up:
+                        del open_list[i]
+                    stats["given_up"] = stats.get("given_up", 0) + len(gave_up)
                 rstat["parents_left"] = len(open_list)
                 if stuck and all(i in stuck for i in open_list) and r + 1 < rounds:
                     pass                                            # (stuck nodes are simply retried with the next round's budget)
-            stats["unfinished"] = len(open_list)
+            stats["unfinished"] = len(open_list) + stats.get("given_up", 0)
             return dict(v=v, obj=obj, status=status, lower_bound=lb, nodes=nodes, pivots=pivots, stats=out["stats"], handoff=stats)
         finally:
             self.record_open_nodes(False)

@@ -22,7 +22,7 @@ prob = gpu.GpuProblem(model, N_p, N_t, cost, **kw)
 n = x0.shape[0]
 for fn, sn, rd in combos:
     t0 = time.perf_counter()
-    out = prob.solve_handoff(x0, om, midx, first_nodes=fn, sub_nodes=sn, rounds=rd, sub_opts=eval("dict(%s)" % os.environ.get("SUB_KW", "")) or None)
+    out = prob.solve_handoff(x0, om, midx, first_nodes=fn, sub_nodes=sn, rounds=rd, sub_opts=eval("dict(%s)" % os.environ.get("SUB_KW", "")) or None, max_open=(int(os.environ["MAX_OPEN"]) if "MAX_OPEN" in os.environ else None))
     wall = time.perf_counter() - t0
     k = min(n, gold.size)
     rel = (out["obj"][:k] - gold[:k]) / np.maximum(1e-9, np.abs(gold[:k]))
