@@ -579,7 +579,6 @@ static int dual_simplex_impl(dict_t *t, double cutoff)
         if (cur > last_obj + 1e-12 * fmax(1.0, fabs(cur))) { stall = 0; last_obj = cur; } else stall++;
         if (stall > 30 && pert_ok && !t->perturbed) { pert_ok = 0; perturb_costs(t); stall = 0; last_obj = -INFINITY; continue; }
         const int bland = stall > 30;
-        if (getenv("ORC_DEBUG_LP") && t->pivots % 50 == 0) { int nv_ = 0; double sv_ = 0; for (int i = 0; i < m; ++i) { if (t->skip[i]) continue; const int j = t->basic[i]; const double v = fmax(t->lo[j] - t->xB[i], t->xB[i] - t->hi[j]); if (v > ORC_PTOL) { nv_++; sv_ += v; } } fprintf(stderr, "  lp pivots %ld obj %.10f stall %d bland %d infeasible rows %d sum %.3e m %d\n", t->pivots, cur, stall, bland, nv_, sv_, m); }
         /* leaving row: dual devex pricing, largest violation^2 / weight (smallest variable id while stalling) */
         int r = -1; double best_sc = 0.0; int rb = -1; int rb_id = 0x7fffffff;
         for (int i = 0; i < m; ++i) {
