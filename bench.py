@@ -588,7 +588,16 @@ def main():
                 t_c = rd.all_max(t_c)
             rates.append(round(world * n_local / t_c, 1))
             prov.append(round(st_c["n_optimal"] / n_local, 4))
-        result["closed_loop"] = {"steps": args.closed_loop_steps, "value_per_step": rates, "proven_per_step": prov,
+        last_handoff = None
+        if world == 1:      # the last step's inputs once more with sub-tree hand-off: what the steady state costs when its tail has to be proven too
+            xk, wk = prob.inputs()
+            hand = dict(first_nodes=args.node_limit, sub_nodes=max(50, args.node_limit // 2), rounds=4, max_open=64)
+            t0 = time.perf_counter()
+            oh = prob.solve_handoff(xk, wk, midx, **hand)
+            t_h = time.perf_counter() - t0
+            last_handoff = dict(hand, value=round(n_local / t_h, 1), proven_fraction=round(float((oh["status"] == 0).mean()), 4), handed_off=oh["handoff"]["handed_off"],
+                                unfinished=oh["handoff"]["unfinished"])
+        result["closed_loop"] = {"steps": args.closed_loop_steps, "value_per_step": rates, "proven_per_step": prov, "last_step_with_handoff": last_handoff,
                                  "value_last_step": rates[-1], "proven_last_step": prov[-1], "mip_start": not args.closed_loop_cold,
                                  "note": "mld_advance_batch between solves (reference: sim_step_k -> lsim_k)%s; the population drifts out of the seeded regime "
                                          "(x0 in 55..64: most tanks need no heating inside the horizon) towards its steady state and the instances get harder "
