@@ -34,7 +34,7 @@ def main():
     f = fe.get("k_solve", {}).get("kb_per_launch", 0.0)
     w = wr.get("k_solve", {}).get("kb_per_launch", 0.0)
     doc = {
-        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu --exact-sample 0 --handles 1 --closed-loop-steps 6 (two separate passes)",
+        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu --exact-sample 0 --handles 1 --closed-loop-steps 0 (two separate passes)",
         "workload": workload,
         "k_solve": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_raw": (f + w) * 1024.0,
                     "hbm_bytes_fetch_x2": (2 * f + w) * 1024.0},
