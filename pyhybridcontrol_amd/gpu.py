@@ -109,6 +109,24 @@ class GpuModel(object):
         return out
 
 
+def expand_open_nodes(fix, depth, var, val, flag, pos):
+    """The open nodes a stopped depth-first search leaves behind, from its stack (mld_download_open_nodes): `fix` are the fixings the search
+    itself ran under (uint8 per binary, 255 = free), level k of the stack branched on decision-vector entry var[k] (pos maps it to its binary
+    position), currently at val[k]; flag[k] = 1 when both children of that level are accounted for.  Returned: one fixing array per open node --
+    for every level whose sibling has not been visited {levels above at their values, this level flipped}, and last the current path itself.
+    The nodes are pairwise disjoint and together cover exactly what the search had not closed (tests/test_host.py)."""
+    res, path = [], np.array(fix, dtype=np.uint8, copy=True)
+    for k in range(int(depth)):
+        kp = int(pos[int(var[k])])
+        if not flag[k]:
+            f = path.copy()
+            f[kp] = 1 - int(val[k])
+            res.append(f)
+        path[kp] = int(val[k])
+    res.append(path)
+    return res
+
+
 def make_opts(**kw):
     o = _lib.Opts()
     check(_lib.load().mld_opts_default(C.byref(o)))
@@ -381,14 +399,7 @@ class GpuProblem(object):
             stats = dict(first_pass_ms=out["stats"]["solve_ms"], rounds=[], handed_off=0)
 
             def expand(fix, dep, vr, vl, fl):
-                res, path = [], fix.copy()
-                for k in range(int(dep)):
-                    kp = pos[int(vr[k])]
-                    if not fl[k]:
-                        f = path.copy(); f[kp] = 1 - vl[k]; res.append(f)
-                    path[kp] = vl[k]
-                res.append(path)
-                return res
+                return expand_open_nodes(fix, dep, vr, vl, fl, pos)
 
             open_list = {}      # parent -> list of (fixings, lower bound valid for that node)
             for i in np.flatnonzero(status == 2):

@@ -403,3 +403,74 @@ def test_matmul_scalar_broadcast_rule():
     assert np.array_equal(matmul(3.0, A), 3.0 * A)
     with pytest.raises(ValueError):
         matmul(A, np.ones((3, 1)))                                           # a real shape mismatch still fails
+
+
+def test_open_nodes_of_a_stopped_depth_first_search_partition_what_is_left():
+    """sub-tree hand-off: a depth-first search over all assignments of 7 binaries with the kernel's stack protocol (variable,
+    first value, "sibling accounted for"), stopped after every possible number of leaves; the nodes gpu.expand_open_nodes reads off the stack
+    must be pairwise disjoint and cover exactly the leaves not visited yet -- also under fixings the search itself ran with"""
+    import itertools
+    from pyhybridcontrol_amd.gpu import expand_open_nodes
+    rng = np.random.default_rng(11)
+    nb = 7
+    pos = np.arange(nb)                                      # decision-vector index == binary position in this toy
+    for trial in range(6):
+        fix0 = np.full(nb, 255, np.uint8)
+        for j in rng.choice(nb, size=trial % 3, replace=False):
+            fix0[j] = rng.integers(0, 2)
+        free = [j for j in range(nb) if fix0[j] == 255]
+        total = 2 ** len(free)
+        for stop_after in range(0, total + 1, max(1, total // 13)):
+            visited, pruned, stack = [], [], []                 # stack entries: [var, current value, sibling accounted for]
+            state = dict(stopped=None)
+
+            def assignment():
+                a = fix0.copy()
+                for v_, val_, _ in stack:
+                    a[v_] = val_
+                return a
+
+            def dfs():
+                if state["stopped"] is not None:
+                    return
+                if len(visited) + len(pruned) >= stop_after:   # the node limit hits HERE: the current path is still open
+                    state["stopped"] = [list(e) for e in stack]
+                    return
+                a = assignment()
+                rest = [j for j in free if a[j] == 255]
+                if not rest:
+                    visited.append(tuple(int(x) for x in a))
+                    return
+                j = rest[int(rng.integers(len(rest)))]       # the branching variable differs from path to path, as in the solver
+                first = int(rng.integers(0, 2))
+                closed_other = bool(rng.random() < 0.2)      # penalty branching closes the sibling without a node of its own now and then
+                if closed_other:                             # the closed sibling is pruned space from the moment the level is pushed
+                    b = a.copy(); b[j] = 1 - first
+                    for bits in itertools.product((0, 1), repeat=int((b == 255).sum())):
+                        c = b.copy(); c[c == 255] = bits; pruned.append(tuple(int(x) for x in c))
+                stack.append([j, first, 1 if closed_other else 0])
+                dfs()
+                if state["stopped"] is not None:
+                    return
+                if not closed_other:
+                    stack[-1][1], stack[-1][2] = 1 - first, 1
+                    dfs()
+                    if state["stopped"] is not None:
+                        return
+                stack.pop()
+
+            dfs()
+            visited = visited + pruned
+            if state["stopped"] is None:
+                assert len(set(visited)) == total
+                continue
+            st = state["stopped"]
+            nodes = expand_open_nodes(fix0, len(st), [e[0] for e in st], [e[1] for e in st], [e[2] for e in st], pos)
+            covered = []
+            for f in nodes:
+                assert np.all((f == fix0) | (fix0 == 255)), "a node keeps the fixings the search ran under"
+                for bits in itertools.product((0, 1), repeat=int((f == 255).sum())):
+                    c = f.copy(); c[c == 255] = bits; covered.append(tuple(int(x) for x in c))
+            assert len(covered) == len(set(covered)), "open nodes overlap"
+            assert not (set(covered) & set(visited)), "an open node contains visited leaves"
+            assert len(set(covered)) + len(set(visited)) == total, (trial, stop_after, len(set(covered)), len(set(visited)), total)
