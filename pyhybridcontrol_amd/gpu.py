@@ -369,7 +369,7 @@ class GpuProblem(object):
         return depth, var, val, flag
 
     def solve_handoff(self, x0, omega, model_idx=None, fixed_bin=None, rounds=3, first_nodes=None, sub_nodes=None, max_sub=None, sub_opts=None,
-                      max_open=None):
+                      max_open=128):
         """The batch solved with sub-tree hand-off: a first pass over all instances (node limit `first_nodes`, default the problem's), then up to
         `rounds` passes in which the OPEN NODES of the instances that stopped at the limit -- read off their depth-first stacks -- are solved as
         instances of their own (node limit `sub_nodes` each, the parent's incumbent value as cutoff), so the whole device works on the few large
