@@ -55,7 +55,7 @@ def test_handoff_with_a_tiny_first_pass_equals_the_unlimited_search():
     wl, ag, m, p = _cfg2(48, gap_rel=0.0, max_nodes=100000)
     ref = p.solve(ag["x0"], ag["omega"])
     assert np.all(ref["status"] == 0)
-    out = p.solve_handoff(ag["x0"], ag["omega"], first_nodes=3, sub_nodes=12, rounds=30)
+    out = p.solve_handoff(ag["x0"], ag["omega"], first_nodes=3, sub_nodes=12, rounds=30, max_open=None)
     print("handoff:", out["handoff"])
     assert out["handoff"]["handed_off"] >= 3 and len(out["handoff"]["rounds"]) >= 2
     assert np.all(out["status"] == 0), np.unique(out["status"], return_counts=True)
