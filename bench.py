@@ -37,6 +37,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PATTERN_CEILING_GBS = 4103.0     # scripts/micro/sector_rmw.hip on MI355X (profiles/r03_sector_rmw.txt): k_solve's update pattern on every CU at once
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 
 
@@ -543,8 +544,21 @@ def main():
                          "frac_of_measured_copy_rate": round(achieved / share / 6300.0, 4),
                          "phases": {nm: round(float(t / ticks.sum()), 4) for nm, t in zip(phase_names, ticks)},
                          "note": "frac (above) divides the streamed bytes by the WHOLE kernel time; the other phases (row / column selection, cut separation, "
-                                 "set-up, verification) are latency- and LDS-bound and stream nothing that is counted.  6.3 TB/s is the copy rate the guide "
-                                 "measures on this part (MI355X_MICROARCH.md)"}),
+                                 "set-up, verification) stream nothing that is counted.  `achieved` here is the rate a workgroup reaches while it is inside the pivot "
+                                 "routine, times the CUs -- NOT a rate the memory system sees: at any moment only this share of the workgroups is in that phase "
+                                 "(see access_pattern for what the memory system delivers when all of them are).  6.3 TB/s is the copy rate the guide measures on "
+                                 "this part (MI355X_MICROARCH.md)"}),
+                     "access_pattern": {
+                         "ceiling": PATTERN_CEILING_GBS, "unit": "GB/s", "full_rows_ceiling": 6007.0,
+                         "what": "read-modify-write of 38 % of the 64-byte sectors of 107 scattered rows of a private fp64 matrix per iteration, with s_update_rows' lane "
+                                 "layout and loads in flight, on every CU at once and nothing else (scripts/micro/sector_rmw.hip; measured on this part: "
+                                 "profiles/r03_sector_rmw.txt); full_rows_ceiling: the same with every sector active",
+                         "traffic_rate": (round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None),
+                         "frac": (round(traffic / (kernel_ms * 1e-3) / 1e9 / PATTERN_CEILING_GBS, 4) if traffic else None),
+                         "note": "HBM bytes by PMC per launch / kernel time, against what the memory system delivers for this access pattern: the kernel keeps it at about "
+                                 "two thirds of that ceiling ALL launch long although only a quarter of the workgroups are in the update loop at a time "
+                                 "(profiles/r03_resident_workgroups.txt: a workgroup is 40 % slower with 256 resident than with 64) -- the shared memory system, "
+                                 "not the latency of one CU, is the bound; two workgroups per CU buy nothing (DESIGN.md section 6)"},
                      "kernel_ms": round(kernel_ms, 3), "measured_on": "last reference step after the timed region (one launch at a time: HIP events around k_solve on "
                                                                     "the launch stream; in the timed region the launches overlap)"},
         "pipeline": {"handles": H, "value_one_at_a_time": round(world * n_local * len(stats) / elapsed_ref, 2), "ms_per_step_one_at_a_time": round(elapsed_ref / len(stats) * 1e3, 2),
