@@ -29,7 +29,7 @@ class Opts(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("nodes", C.c_int), ("pivots", C.c_int), ("cuts", C.c_int), ("refactors", C.c_int),
                 ("status", C.c_int), ("root_lp", C.c_double), ("root_bound", C.c_double),
-                ("lower_bound", C.c_double), ("work", C.c_double), ("bland", C.c_double), ("rebuilds", C.c_double), ("phase_work", C.c_double * 6)]
+                ("lower_bound", C.c_double), ("work", C.c_double), ("bland", C.c_double), ("rebuilds", C.c_double), ("phase_work", C.c_double * 6), ("flips", C.c_double)]
 
 
 def build(force=False):
@@ -80,7 +80,7 @@ def solve_milp(q, G, h, lb, ub, is_bin, x_start=None, **kw):
                              C.byref(o), _p(x), C.byref(obj), C.byref(st))
     return dict(status=STATUS[s], obj=obj.value, x=x if (np.isfinite(obj.value) or s == 4) else None, nodes=st.nodes,
                 pivots=st.pivots, cuts=st.cuts, refactors=st.refactors, root_lp=st.root_lp,
-                root_bound=st.root_bound, lower_bound=st.lower_bound, work=st.work, bland=st.bland, rebuilds=st.rebuilds, phase_work=list(st.phase_work))
+                root_bound=st.root_bound, lower_bound=st.lower_bound, work=st.work, bland=st.bland, rebuilds=st.rebuilds, phase_work=list(st.phase_work), flips=st.flips)
 
 
 def _solve_start(P, q, G, h, lb, ub, is_bin, x_start, **kw):
@@ -102,7 +102,7 @@ def _solve_start(P, q, G, h, lb, ub, is_bin, x_start, **kw):
                                    C.byref(o), _p(xs), _p(x), C.byref(obj), C.byref(st))
     return dict(status=STATUS[s], obj=obj.value, x=x if (np.isfinite(obj.value) or s == 4) else None, nodes=st.nodes,
                 pivots=st.pivots, cuts=st.cuts, refactors=st.refactors, root_lp=st.root_lp,
-                root_bound=st.root_bound, lower_bound=st.lower_bound, work=st.work, bland=st.bland, rebuilds=st.rebuilds, phase_work=list(st.phase_work))
+                root_bound=st.root_bound, lower_bound=st.lower_bound, work=st.work, bland=st.bland, rebuilds=st.rebuilds, phase_work=list(st.phase_work), flips=st.flips)
 
 
 def solve_milp_batch(qs, Gs, hs, lb, ub, is_bin, threads=0, **kw):
