@@ -52,7 +52,7 @@ def test_cutoff_semantics():
 def test_handoff_with_a_tiny_first_pass_equals_the_unlimited_search():
     """first pass of 3 nodes per instance, 12 per open node afterwards: the instances that need a tree are handed off, several rounds deep; the merged
     result is the exact optimum"""
-    wl, ag, m, p = _cfg2(48, gap_rel=0.0, max_nodes=100000)
+    wl, ag, m, p = _cfg2(48, gap_rel=0.0, max_nodes=100000, cut_rounds=1)       # (one cut round: the full loop closes all but one of these instances at the root)
     ref = p.solve(ag["x0"], ag["omega"])
     assert np.all(ref["status"] == 0)
     out = p.solve_handoff(ag["x0"], ag["omega"], first_nodes=3, sub_nodes=12, rounds=30, max_open=None)
