@@ -58,9 +58,9 @@ def test_bench_workload_within_gap_of_highs_optimum():
     within = float((rel <= GAP + 1e-9).mean())
     proven = float((out["status"] == 0).mean())
     print("bench parity: proven %.4f within-gap %.4f worst %.4f node-limited %d" % (proven, within, rel.max(), int((out["status"] == 2).sum())))
-    assert proven >= 0.99, proven                       # (round 1: 0.979 at NodeLimit 400)
-    assert within >= 0.995, within
-    assert rel.max() <= 0.10, "an incumbent more than 10 %% above the optimum: %g" % rel.max()
+    assert proven >= 0.995, proven                      # (measured 0.9990; round 2: 0.9941, round 1: 0.979 at NodeLimit 400)
+    assert within >= 0.997, within
+    assert rel.max() <= 0.06, "an incumbent more than 6 %% above the optimum: %g" % rel.max()      # (measured 0.027; round 2: 0.099)
     wl = dict(N_p=N_p, N_tilde=N_t)
     for i in list(range(0, 1024, 37)) + list(np.where(out["status"] == 2)[0][:8]):      # certificates on the original rows
         ag = dict(agents[int(midx[i])], x0=x0[i][None], omega=om[i][None])
@@ -77,7 +77,7 @@ def test_bench_workload_exact_contract():
     rel = _check_against_optimum(out, opt, 1e-6)
     proven = out["status"] == 0
     print("exact contract: proven %d of %d, worst |obj-opt|/|opt| over proven %.3g" % (proven.sum(), proven.size, np.abs(rel[proven]).max()))
-    assert proven.mean() >= 0.97, proven.mean()
+    assert proven.mean() >= 0.98, proven.mean()          # (measured 255 of 256)
     assert np.abs(rel[proven]).max() <= 2e-6
 
 
@@ -128,4 +128,4 @@ def test_cfg5_shape_against_highs_at_size():
     assert np.all(obj[ok][claimed] - hi[claimed] <= 1e-2 * np.abs(obj[ok][claimed]) + 1e-6 * scale[claimed]), "OPTIMAL outside the gap of HiGHS's incumbent"
     rel = (obj[ok] - hi) / scale
     print("cfg5: proven %d of %d, within 1 %% of HiGHS's incumbent %d of %d, worst %.3f" % ((st == 0).sum(), nb, (rel <= 1e-2).sum(), ok.sum(), rel.max()))
-    assert (st == 0).mean() >= 0.25
+    assert (st == 0).mean() >= 0.40                     # (52-59 % over the binaries of round 3; round 2: 41-46 %)

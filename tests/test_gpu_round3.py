@@ -45,8 +45,8 @@ def test_timed_scenario_set_against_highs_optimum():
     rel = _check_against_optimum(out, gold["obj"][:n], GAP)
     proven, within = float((out["status"] == 0).mean()), float((rel <= GAP + 1e-9).mean())
     print("timed set: proven %.4f within-gap %.4f worst %.4f node-limited %d" % (proven, within, rel.max(), int((out["status"] == 2).sum())))
-    assert proven >= 0.99 and within >= 0.995
-    assert rel.max() <= 0.10, "an incumbent more than 10 %% above the optimum: %g" % rel.max()      # (measured 0.064)
+    assert proven >= 0.995 and within >= 0.997          # (measured 0.9990 / 0.9990; before the cut loop's patience was raised 0.9961 / 0.9971)
+    assert rel.max() <= 0.06, "an incumbent more than 6 %% above the optimum: %g" % rel.max()      # (measured 0.019)
 
 
 def test_steady_state_closed_loop_instances_against_highs_optimum():
@@ -63,7 +63,7 @@ def test_steady_state_closed_loop_instances_against_highs_optimum():
     rel = _check_against_optimum(sub, gold["obj"][ok], GAP)
     proven, within = float((out["status"] == 0).mean()), float((rel <= GAP + 1e-9).mean())
     print("steady state: proven %.4f within-gap %.4f worst %.4f" % (proven, within, rel.max()))
-    assert proven >= 0.93 and within >= 0.96
+    assert proven >= 0.96 and within >= 0.975           # (measured 0.984 / 0.984; round-3 start 0.945 / 0.973)
     # the tail: 99 % of the steady-state instances end within 10 % of the optimum.  The rest is where the search is weakest: an
     # instance whose LP bound is blind to a soft-constraint penalty until the last binary of a dive is fixed (fixture instance 245: LP value 0.65 at
     # depth 62 of the dive, 16.7 at depth 63 for both children) can end at the node limit several times above its optimum of 1.25 -- still a feasible,
