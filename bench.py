@@ -434,6 +434,9 @@ def main():
             prob.advance()                          # next MPC step of the same scenarios: plant update + forecast shift, on device
             if not args.closed_loop_cold:
                 prob.warm_start_from_previous(1)    # warm_start=True of the reference's solve(): the previous plan, moved on one step, as MIP start
+            if os.environ.get("BENCH_CL_TRACE"):      # diagnostics: the inputs of the solve that follows, for a post-mortem replay
+                xk_, wk_ = prob.inputs()
+                np.savez("/tmp/cl_in.npz", x0=xk_, omega=wk_, midx=midx, step=-1)
         else:
             prob.select(state["k"] % n_sets)        # next scenario set: device-to-device copy
             state["k"] += 1
@@ -608,7 +611,12 @@ def main():
         # closed loop: the SAME scenarios advanced step by step (plant update with the inputs just computed, forecast shifted)
         rates, prov = [], []
         progress("closed loop: %d steps" % args.closed_loop_steps)
-        for _ in range(args.closed_loop_steps):
+        cl_trace = os.environ.get("BENCH_CL_TRACE")       # diagnostics: post-mortem trace of the solver's workgroups + the inputs of every closed-loop step
+        if cl_trace:
+            prob.debug_trace(os.path.join(cl_trace, "cl_trace.bin"))
+        for k_cl in range(args.closed_loop_steps):
+            if cl_trace:
+                progress("closed loop step %d" % k_cl)
             sync()
             t0 = time.perf_counter()
             st_c = step(closed_loop=True)

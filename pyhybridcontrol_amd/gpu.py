@@ -1,5 +1,6 @@
 """Thin object wrappers over the C ABI handles of libmldgpu (mld_model_t / mld_problem_t)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -326,6 +327,14 @@ class GpuProblem(object):
                                                ip(nodes), ip(pivots)))
         return dict(v=v, obj=obj, status=status, lower_bound=lbnd, nodes=nodes, pivots=pivots)
 
+    def debug_trace(self, path):
+        """diagnostics: every resident workgroup of the solver writes (instance, stage, pivots, queue position) into a file-backed host buffer that
+        survives a GPU fault (internal entry mld_debug_trace; None switches it off).  Read it with numpy.fromfile(path, numpy.int32).reshape(-1, 16)."""
+        lib = _lib.load()
+        lib.mld_debug_trace.restype = C.c_int
+        lib.mld_debug_trace.argtypes = [C.c_void_p, C.c_char_p]
+        check(lib.mld_debug_trace(self._h, None if path is None else str(path).encode()))
+
     def telemetry(self):
         """per-instance in-kernel latency (ns) and dictionary rows updated; row_bytes = bytes per row"""
         b = self.batch
@@ -423,6 +432,8 @@ class GpuProblem(object):
                     break
                 self.upload(x0[par], omega[par], mi[par] if mi is not None else None, fix)
                 self.set_cutoffs(obj[par])
+                if os.environ.get("MLD_HANDOFF_DUMP"):      # diagnostics: the sub-batch about to be solved (post-mortem replay)
+                    np.savez(os.environ["MLD_HANDOFF_DUMP"], x0=x0[par], omega=omega[par], midx=(mi[par] if mi is not None else np.zeros(par.size, np.int32)), fix=fix, cutoff=obj[par], round=r)
                 st = self.solve_resident()
                 sub = self.download()
                 d2, v2, l2, f2 = self.open_nodes()
