@@ -257,8 +257,8 @@ def _against_gold(out, k_max, tag="solve_cfg4_bench.npz"):
 
 def exact_leg(prob, x0, om, midx, n_exact, args):
     """north star: "within 1e-6 objective of CPU reference".  The same problem at gap 1e-6 on the first n_exact instances of the shard, objectives
-    checked against the committed HiGHS optima.  `value_exact` is measured WITH sub-tree hand-off (GpuProblem.solve_handoff: a first pass of 1000
-    nodes per instance, then the open nodes of the unfinished instances as instances of their own, 800 nodes each, up to 8 rounds, a tree with more
+    checked against the committed HiGHS optima.  `value_exact` is measured WITH sub-tree hand-off (GpuProblem.solve_handoff: a first pass of 300
+    nodes per instance, then the open nodes of the unfinished instances as instances of their own, 200 nodes each, up to 14 rounds, a tree with more
     than 160 open nodes given up) -- wall clock of the whole procedure, host merging included; `single_pass` is round 2's measurement: one workgroup
     per instance, NodeLimit 20 000, where one instance running to its limits holds the launch while the other CUs idle."""
     n_exact = x0.shape[0] if n_exact < 0 else min(n_exact, x0.shape[0])
@@ -268,7 +268,8 @@ def exact_leg(prob, x0, om, midx, n_exact, args):
     prob.upload(xs[:n_exact], ws[:n_exact], midx[:n_exact])
     prob.solve_resident()
     prob.set_opts(gap_rel=1e-6, max_nodes=20000, max_pivots=400000)
-    hand = dict(first_nodes=1000, sub_nodes=800, rounds=8, max_open=160)
+    hand = dict(first_nodes=300, sub_nodes=200, rounds=14, max_open=160)      # (scripts/gpu_handoff_probe.py on the final round-3 binary: 5.2 k/s at 99.96 % proven;
+                                                                              #  1000 / 800 / 8: 3.1 k/s at 99.976 %, 600 / 600 / 8: 3.7 k/s, 400 / 400 / 10: 4.6 k/s, 300 / 150 / 16: 5.5 k/s at 99.957 %)
     t0 = time.perf_counter()
     out = prob.solve_handoff(x0[:n_exact], om[:n_exact], midx[:n_exact], **hand)
     wall = time.perf_counter() - t0
