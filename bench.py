@@ -309,7 +309,7 @@ def exact_leg(prob, x0, om, midx, n_exact, args):
 def handoff_leg(prob, x0, om, midx, args):
     """the bench's own contract (MIPGap / NodeLimit of the timed region) on scenario set 0 with sub-tree hand-off: what the node-limited tail of a
     step becomes when its open nodes are re-queued (quality mode: slower than one pass, nearly everything proven)"""
-    hand = dict(first_nodes=args.node_limit, sub_nodes=max(50, args.node_limit // 2), rounds=4, max_open=64)
+    hand = dict(first_nodes=args.node_limit, sub_nodes=max(50, args.node_limit // 2), rounds=4, max_open=64)      # (gpu_handoff_probe.py: 300 / 200 / 8 is 12 % faster at the same proven share, but leaves a reported gap of up to 33 % on the instances it gives up; this setting at most 4.7 %)
     t0 = time.perf_counter()
     out = prob.solve_handoff(x0, om, midx, **hand)
     wall = time.perf_counter() - t0
@@ -630,7 +630,7 @@ def main():
         last_handoff = None
         if world == 1:      # the last step's inputs once more with sub-tree hand-off: what the steady state costs when its tail has to be proven too
             xk, wk = prob.inputs()
-            hand = dict(first_nodes=args.node_limit, sub_nodes=max(50, args.node_limit // 2), rounds=4, max_open=64)
+            hand = dict(first_nodes=args.node_limit, sub_nodes=max(50, args.node_limit // 2), rounds=4, max_open=64)      # (gpu_handoff_probe.py: 300 / 200 / 8 is 12 % faster at the same proven share, but leaves a reported gap of up to 33 % on the instances it gives up; this setting at most 4.7 %)
             t0 = time.perf_counter()
             oh = prob.solve_handoff(xk, wk, midx, **hand)
             t_h = time.perf_counter() - t0
