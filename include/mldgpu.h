@@ -84,8 +84,7 @@ typedef struct {
                               k_milp_lds (csrc/milp_lds.inc) instead of the dense-dictionary kernel; instances it cannot finish are
                               re-solved by the dense kernel in the same call, bit11 leave those instances at status -1 instead (counting only),
                               bit12 k_milp_lds profile slots = phases inside the simplex (mld_debug_profile), bit13 no anti-stalling cost
-                              perturbation in the dual simplex (A/B of round 3's change), bit14 EXPERIMENTAL long-step (bound flipping) ratio test in the root LP, bit15 EXPERIMENTAL reduced-cost row in LDS,
-                              bit16 EXPERIMENTAL compact c-MIR score lines in LDS (bits 15, 16 are read when the problem is created). */
+                              perturbation in the dual simplex (A/B of round 3's change), bit14 no long-step (bound flipping) ratio test in the root LP (A/B). */
     double time_limit;     /* seconds per INSTANCE on the device clock (Gurobi TimeLimit; the reference passes TimeLimit=20 with every solve,
                               examples/residential_mg_with_pv_and_dewhs/micro_grid_control_simulation.py:232, forwarded by
                               controllers/controller_base.py:509-512): the branch-and-bound of an instance ends once it has run that long, like

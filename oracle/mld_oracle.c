@@ -41,7 +41,7 @@
                                 * Paired runs, 2048 bench + 256 steady-state instances, patience 2 -> 10: row updates -12 % / -1 %, per-instance geometric mean -3 % on both,
                                 * node-limited 5 -> 1 and 10 -> 5; environment ORC_PATIENCE overrides (study) */
 #ifndef ORC_BFRT_DEFAULT
-#define ORC_BFRT_DEFAULT 0     /* long-step (bound flipping) dual ratio test: 0 off, 1 root LP only (csrc/problem.inc), 2 + cut rounds, 3 everywhere; environment ORC_BFRT overrides (study) */
+#define ORC_BFRT_DEFAULT 1     /* long-step (bound flipping) dual ratio test: 0 off, 1 root LP only (csrc/problem.inc), 2 + cut rounds, 3 everywhere; environment ORC_BFRT overrides (study) */
 #endif
 #define ORC_PIV_ABS 1e-7
 #define ORC_PIV_REL 1e-7
@@ -660,8 +660,8 @@ static int dual_simplex_impl(dict_t *t, double cutoff)
             /* Long-step ("bound flipping") ratio test for boxed variables (Fourer 1994; Maros 2003): the dual objective rises along the step with slope =
              * the leaving row's violation; passing the breakpoint of a BOXED non-basic variable j lowers the slope by |a_rj| (hi_j - lo_j) and j simply
              * moves to its other bound -- no pivot.  Groups of breakpoints inside one Harris window are passed together while the slope stays positive;
-             * the entering variable is the largest |a| of the first group that cannot be passed.  Round 3: EXPERIMENTAL, off by default (ORC_BFRT=1 = root
-             * LP only; kernel: opts.reserved bit 14) -- on the 2048 bench instances -15 % row updates (root LP -40 %), on the GPU -3 % bytes. */
+             * the entering variable is the largest |a| of the first group that cannot be passed.  On for the root LP (ORC_BFRT_DEFAULT 1; ORC_BFRT=0 and the kernel's
+             * opts.reserved bit 14 switch it off for an A/B) -- on the 2048 bench instances -15 % row updates (root LP -40 %), on the GPU -3 % bytes. */
             unsigned char *gone = (unsigned char *)t->tmp_row;
             memset(gone, 0, n);
             double slope = viol;

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmldgpu.so")
+LIB_PATH = os.environ.get("MLDGPU_LIB") or os.path.join(_HERE, "libmldgpu.so")      # (MLDGPU_LIB: a diagnostic build of the same library, scripts/ only)
 
 MAT_NAMES = ("A", "B1", "B2", "B3", "B4", "b5", "C", "D1", "D2", "D3", "D4", "d5",
              "E", "F1", "F2", "F3", "F4", "f5", "G", "Psi")

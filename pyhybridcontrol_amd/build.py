@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mldgpu.hip")
-OUT = os.path.join(HERE, "libmldgpu.so")
+OUT = os.environ.get("MLD_OUT") or os.path.join(HERE, "libmldgpu.so")      # (MLD_OUT + MLD_CXXFLAGS: a diagnostic variant beside the product, e.g. -DMLD_ASSERT)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
