@@ -37,8 +37,41 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PATTERN_CEILING_GBS = 4103.0     # scripts/micro/sector_rmw.hip on MI355X (profiles/r03_sector_rmw.txt): k_solve's update pattern on every CU at once
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+
+
+def pattern_ceiling():
+    """what the memory system delivers for k_solve's update pattern on every CU at once (scripts/micro/sector_rmw.hip): read from the committed
+    measurement, newest round first -- (GB/s at 38 % active sectors, GB/s with every sector active, file)"""
+    import re
+    for name in ("r04_sector_rmw.txt", "r03_sector_rmw.txt"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        part = full = None
+        for line in open(path):
+            m = re.search(r"mode 0 .*wgs\s+256 threads 512 sector\s+64 B active\s+([0-9.]+)%.*?([0-9.]+)\s+GB/s", line)
+            if not m:
+                continue
+            if abs(float(m.group(1)) - 38.0) < 0.5 and part is None:
+                part = float(m.group(2))
+            if abs(float(m.group(1)) - 100.0) < 0.5 and full is None:
+                full = float(m.group(2))
+        if part:
+            return part, full, "profiles/" + name
+    return None, None, None
+
+
+def parse_kwargs(text):
+    """'mir_per_round=10,cut_rounds=4' -> dict (ints / floats); replaces the eval() of round 3"""
+    out = {}
+    for item in filter(None, (t.strip() for t in text.split(","))):
+        k, _, v = item.partition("=")
+        try:
+            out[k.strip()] = int(v)
+        except ValueError:
+            out[k.strip()] = float(v)
+    return out
 
 
 def parse():
@@ -61,7 +94,9 @@ def parse():
                     "the workgroups of step k+1 move onto the CUs the stragglers of step k leave idle; 1 = one step after another")
     ap.add_argument("--reference-steps", type=int, default=2, help="steps solved strictly one after another after the timed region (roofline, latency, value_one_at_a_time)")
     ap.add_argument("--reserved", type=int, default=0, help="diagnostics: opts.reserved bits for the solver (include/mldgpu.h), e.g. 1024 = the experimental LDS-resident branch-and-cut")
-    ap.add_argument("--solver-opts", type=str, default="", help="diagnostics: extra solver options as python kwargs, e.g. 'mir_per_round=10'")
+    ap.add_argument("--solver-opts", type=str, default="", help="diagnostics: extra solver options, e.g. 'mir_per_round=10,cut_rounds=4'")
+    ap.add_argument("--fixed-cost", action="store_true", help="keep one cost for every timed step (round 3) instead of new prices per step (mld_problem_set_cost inside the timed region)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the cfg5 / MIQP / single-instance legs after the timed region")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank rehearsal on ONE GPU: every rank on device 0, gather over the TCP side channel")
     return ap.parse_args()
 
@@ -327,6 +362,138 @@ def handoff_leg(prob, x0, om, midx, args):
     return res
 
 
+
+def cfg5_leg():
+    """BASELINE configs[4] (n_h = 15, N_p = 48: n = 2303, 784 binaries, m = 1764) on the 128 instances that have a committed HiGHS bracket
+    (tests/golden/solve_cfg5.npz): proven share, distance from HiGHS's incumbent, rate, dictionary bytes per instance, and the fp32 condensing
+    roofline at that shape (16 jittered models per launch)."""
+    from pyhybridcontrol_amd import gpu, host, synthetic as syn
+    gpath = os.path.join(ROOT, "tests", "golden", "solve_cfg5.npz")
+    if not os.path.exists(gpath):
+        return None
+    gold = np.load(gpath)
+    nb = int(gold["n_scen"])
+    wl = syn.make_workload("cfg5", batch=nb)
+    ag = wl["agents"][0]
+    d, N_p, N_t = ag["dims"], wl["N_p"], wl["N_tilde"]
+    m = gpu.GpuModel([ag["mats"]], d)
+    opts = dict(gap_rel=1e-2, max_nodes=400, max_pivots=160000)
+    p = gpu.GpuProblem(m, N_p, N_t, host.cost_from_atoms(ag["atoms"], d, N_p, N_t), **opts)
+    p.upload(ag["x0"], ag["omega"])
+    t0 = time.perf_counter()
+    st = p.solve_resident()
+    wall = time.perf_counter() - t0
+    out, tel = p.download(), p.telemetry()
+    ok = np.isfinite(gold["obj"]) & np.isfinite(gold["dual_bound"])
+    rel = (out["obj"][ok] - gold["obj"][ok]) / np.maximum(1e-9, np.abs(gold["obj"][ok]))
+    piv = int(out["pivots"].sum())
+    upd = 2.0 * int(tel["rows_updated"].sum()) * tel["row_bytes"] + piv * (2 * 8.0 * (p.n + 1) + 2 * 8.0 * p.n + 64.0 * p.m)
+    res = dict(workload="BASELINE cfg5 shape, %d instances of one agent (n=%d, %d binaries, m=%d)" % (nb, p.n, p.n_bin, p.m), options=opts,
+               value=round(nb / wall, 2), unit="agent-solves/s", kernel_ms=round(float(st["solve_ms"]), 1),
+               proven_fraction=round(float((out["status"] == 0).mean()), 4), no_incumbent=int((~np.isfinite(out["obj"])).sum()),
+               within_1pct_of_highs_incumbent=round(float((rel <= 1e-2).mean()), 4), worst_rel_above_highs_incumbent=round(float(rel.max()), 4),
+               below_highs_dual_bound=int((out["obj"][ok] < gold["dual_bound"][ok] - 1e-6 * np.abs(gold["obj"][ok])).sum()),
+               nodes_per_instance=round(float(out["nodes"].mean()), 1), pivots_per_instance=round(piv / nb, 1),
+               bytes_per_instance=int(upd / nb), hbm_rate_GBs=round(upd / (float(st["solve_ms"]) * 1e-3) / 1e9, 1),
+               oracle="tests/golden/solve_cfg5.npz (scipy HiGHS, mip_rel_gap 1e-4, 240 s per instance: incumbent and dual bound)",
+               note="128 instances keep only half of the 256 workgroups busy: the rate is that of a partly filled device (a per-GPU shard of cfg5 is 1024)")
+    p.close(); m.close()
+    # fp32 condensing at the shape (configs[4]: 'fp32 condensing ... rocprof roofline reported'): 16 jittered agents per launch
+    mods = []
+    for a in range(16):
+        rng = np.random.Generator(np.random.PCG64(syn.CONFIGS["cfg5"]["seed"] * 1000 + a))
+        mods.append(syn.make_agent(syn.CONFIGS["cfg5"]["n_h"], rng)[0])
+    mm = gpu.GpuModel(mods, d)
+    nx, ny, nc, nw, nv = d["nx"], d["ny"], d["nc"], d["nomega"], mm.nv
+    cols = N_t * nv + nx + N_t * nw + 1
+    small = 8.0 * ((nx + ny + nc) * (nx + nv + nw + 1) + nc * ny)
+    b64, b32 = 8.0 * N_t * (nc + nx + ny) * cols + small, 4.0 * N_t * (nc + nx + ny) * cols + small
+    ms64 = min(mm.condense_device(N_t) for _ in range(5))
+    ms32 = min(mm.condense_device(N_t, f32=True) for _ in range(5))
+    res["condense"] = {"models": 16, "bytes_per_model_f32": int(b32), "kernel_ms_f32": round(ms32, 4), "achieved_f32": round(16 * b32 / (ms32 * 1e-3) / 1e9, 1),
+                       "frac_f32": round(16 * b32 / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_model_f64": int(b64), "kernel_ms_f64": round(ms64, 4),
+                       "achieved_f64": round(16 * b64 / (ms64 * 1e-3) / 1e9, 1), "frac_f64": round(16 * b64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "unit": "GB/s", "peak": HBM_PEAK_GBS, "bound": "hbm", "kernel": "k_condense_model / k_condense_blocks + k_condense_flat<float|double>",
+                       "note": "SURVEY 8d algorithmic bytes (outputs + inputs) / min-of-5 HIP-event time; the block arithmetic stays fp64 (inner dimension nx = 15: no MFMA), "
+                               "every output element is rounded once to fp32 on its way to HBM"}
+    mm.close()
+    return res
+
+
+def miqp_leg(n_inst=512):
+    """The quadratic-cost path (north star: 'batched MIQP'): BASELINE cfg3 shape with the MIQP variant's Q_x = 1e-3 I, same MIPGap /
+    NodeLimit as the timed region, next to the MILP of the same instances."""
+    from pyhybridcontrol_amd import gpu, host, synthetic as syn
+    res = {}
+    for quad in (False, True):
+        wl = syn.make_workload("cfg3", batch=n_inst, quadratic=quad)
+        ag = wl["agents"][0]
+        d = ag["dims"]
+        m = gpu.GpuModel([ag["mats"]], d)
+        p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"]), gap_rel=1e-2, max_nodes=800, max_pivots=40000)
+        p.upload(ag["x0"], ag["omega"])
+        p.solve_resident()                      # (first solve: learns the queue order)
+        t0 = time.perf_counter()
+        st = p.solve_resident()
+        wall = time.perf_counter() - t0
+        out = p.download()
+        res["miqp" if quad else "milp_same_instances"] = dict(value=round(n_inst / wall, 1), kernel_ms=round(float(st["solve_ms"]), 1),
+                                                              proven_fraction=round(float((out["status"] == 0).mean()), 4), no_incumbent=int((~np.isfinite(out["obj"])).sum()),
+                                                              nodes_per_instance=round(float(out["nodes"].mean()), 1), pivots_per_instance=round(float(out["pivots"].mean()), 1))
+        p.close(); m.close()
+    res.update(unit="agent-solves/s", instances=n_inst,
+               workload="BASELINE cfg3 shape (n_h=7, N_p=24), Q_x = 1e-3 I added to the example's linear atoms; MIPGap 1e-2, NodeLimit 800; parity: tests/test_gpu_miqp.py")
+    return res
+
+
+def single_instance_leg(agents, N_p, N_t, x0, om, midx, latency_ns, opts, n_hard=64):
+    """What ONE solve() call of the reference costs here (controller_base.py:491-540 solves one instance per call): the hardest instances of the
+    last reference step (largest in-kernel latency), (i) each alone through MpcController.solve -- upload, K3, K5/K6, download of one instance --
+    and (ii) all n_hard as one batch through the batched harness."""
+    import pyhybridcontrol_amd as phc
+    from pyhybridcontrol_amd import gpu, host
+    order = np.argsort(-latency_ns)
+    top1 = order[: max(1, len(order) // 100)]
+    hard = order[:n_hard]
+    # batch-1 calls: controllers for the (at most 4) agents that own most of the hardest 1 %
+    ag_ids, counts = np.unique(midx[top1], return_counts=True)
+    pick = ag_ids[np.argsort(-counts)][:4]
+    lat1, n_calls, worse = [], 0, 0
+    for a in pick:
+        ag = agents[int(a)]
+        d = ag["dims"]
+        ctrl = phc.MpcController(phc.MldModel(ag["mats"], nu_l=d["nu_l"]), N_p=N_p, **opts)
+        ctrl.set_std_obj_atoms(**ag["atoms"])
+        ctrl.build()
+        mine = [i for i in top1 if midx[i] == a][:8]
+        ctrl.solve(0, x_k=x0[mine[0]], omega_tilde_k=om[mine[0]], warm_start=False)      # (first call: allocations)
+        for i in mine:
+            t0 = time.perf_counter()
+            ctrl.solve(0, x_k=x0[i], omega_tilde_k=om[i], warm_start=False)
+            lat1.append((time.perf_counter() - t0) * 1e3)
+            n_calls += 1
+        del ctrl
+    lat1 = np.sort(np.array(lat1))
+    # one batch of the n_hard hardest
+    d = agents[0]["dims"]
+    model = gpu.GpuModel([a["mats"] for a in agents], d)
+    prob = gpu.GpuProblem(model, N_p, N_t, host.stack_costs([host.cost_from_atoms(a["atoms"], d, N_p, N_t) for a in agents]), **opts)
+    prob.solve(x0[hard], om[hard], midx[hard])
+    t0 = time.perf_counter()
+    out = prob.solve(x0[hard], om[hard], midx[hard])
+    wall = (time.perf_counter() - t0) * 1e3
+    tel = np.sort(prob.telemetry()["latency_ns"]) * 1e-6
+    res = dict(batch_1=dict(calls=n_calls, agents=int(len(pick)), p50_ms=round(float(lat1[len(lat1) // 2]), 2), p99_ms=round(float(lat1[min(len(lat1) - 1, int(len(lat1) * 0.99))]), 2),
+                            max_ms=round(float(lat1[-1]), 2), what="wall time of MpcController.solve(k, x_k, omega_tilde_k) per call, instances drawn from the hardest 1 % of the step"),
+               batch_64=dict(instances=int(len(hard)), wall_ms=round(wall, 2), p50_ms=round(float(tel[len(tel) // 2]), 2), p99_ms=round(float(tel[min(len(tel) - 1, int(len(tel) * 0.99))]), 2),
+                             max_ms=round(float(tel[-1]), 2), proven_fraction=round(float((out["status"] == 0).mean()), 4),
+                             what="the %d hardest instances of the step as one batch: wall time of the call and in-kernel latency per instance" % len(hard)),
+               in_step_latency_ms=dict(p50=round(float(np.median(latency_ns[hard])) * 1e-6, 2), max=round(float(latency_ns[hard].max()) * 1e-6, 2),
+                                       what="the same instances inside the full 32768-instance step (every CU busy)"))
+    prob.close(); model.close()
+    return res
+
+
 class SideChannelGather(object):
     """--rehearse: the result gather over the TCP side channel (several ranks share one GPU, where RCCL cannot run)"""
 
@@ -340,7 +507,7 @@ class SideChannelGather(object):
         return np.stack([np.frombuffer(b, dtype=np.float64).reshape(loc.shape) for b in self.rd.all_gather_bytes(loc.tobytes())])
 
 
-def run_pipelined(probs, count, state, n_sets, gatherer):
+def run_pipelined(probs, count, state, n_sets, gatherer, costs=None):
     """`count` steps over the handles `probs`: step j is launched on handle j % H as soon as that handle's previous step has been finished
     (statistics, learnt queue order, result gather); returns the per-step statistics once every step has finished.  The order of
     launches, finishes and gathers depends on (count, H) alone -- never on which solve happens to end first -- so every rank issues the
@@ -355,6 +522,8 @@ def run_pipelined(probs, count, state, n_sets, gatherer):
                 gatherer.gather_results(q)
             pending[j % H] = None
         if j < count:
+            if costs is not None:
+                q.set_cost(costs[state["k"] % len(costs)])      # this step's prices (the reference rebuilds its objective before every solve)
             q.select(state["k"] % n_sets)
             state["k"] += 1
             q.launch()
@@ -379,7 +548,7 @@ def main():
     d = agents[0]["dims"]
     model = gpu.GpuModel([a["mats"] for a in agents], d)
     cost = host.stack_costs([host.cost_from_atoms(a["atoms"], d, N_p, N_t) for a in agents])
-    prob = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit, reserved=args.reserved, **eval("dict(%s)" % args.solver_opts))
+    prob = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit, reserved=args.reserved, **parse_kwargs(args.solver_opts))
     n_local = x0.shape[0]
     exact = None
     if world == 1 and args.exact_sample != 0:
@@ -389,11 +558,11 @@ def main():
     if world == 1 and args.exact_sample != 0:
         progress("hand-off leg at the bench's own contract")
         hand1 = handoff_leg(prob, x0, om, midx, args)
-    progress("staging %d scenario sets" % (args.warmup + args.steps + max(1, args.reference_steps) + 2))
+    progress("staging %d scenario sets" % (args.warmup + args.steps + max(1, args.reference_steps) + 5))
     prob.upload(x0, om, midx)                       # inputs resident in HBM before the timed region
     # fresh scenario sets for every step (set 0 = the shard's own scenarios), all resident in HBM before the timed region
     from pyhybridcontrol_amd import synthetic as syn
-    n_sets = args.warmup + args.steps + max(1, args.reference_steps) + 2
+    n_sets = args.warmup + args.steps + max(1, args.reference_steps) + 5      # (+ 3 for the fixed-cost continuity steps, + 2 spare)
     x0_sets = np.empty((n_sets,) + x0.shape)
     om_sets = np.empty((n_sets,) + om.shape)
     x0_sets[0], om_sets[0] = x0, om
@@ -404,13 +573,24 @@ def main():
     H = max(1, args.handles)
     probs = [prob]
     for _ in range(1, H):
-        q = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit, reserved=args.reserved, **eval("dict(%s)" % args.solver_opts))
+        q = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit, reserved=args.reserved, **parse_kwargs(args.solver_opts))
         q.upload(x0, om, midx); q.stage(x0_sets, om_sets)
         probs.append(q)
     if H > 1:
         for q in probs:
             q.use_stream()
     del x0_sets, om_sets
+    # prices move with the clock: step k of the timed region starts 15 minutes after step k - 1, so its tariff vector is the previous one moved on by
+    # one control period (the reference recomputes q_z / q_mu from the tariff before every solve, micro_grid_control_simulation.py:194-198,229).
+    # The weight tables are host data prepared before the region; handing them to the device (mld_problem_set_cost) is part of every timed step.
+    cost_sets = None
+    if not args.fixed_cost:
+        import datetime as _dt
+        t_base = _dt.datetime(2018, 12, 10, 5, 0)
+        cost_sets = []
+        for t in range(n_sets):
+            t0 = t_base + _dt.timedelta(seconds=syn.TS * t)
+            cost_sets.append(host.stack_costs([host.cost_from_atoms(syn.make_cost(syn.CONFIGS["cfg4"]["n_h"], N_t, a["params"], t0=t0), d, N_p, N_t) for a in agents]))
     gatherer = None
     if world > 1:
         if args.rehearse:
@@ -439,6 +619,8 @@ def main():
                 xk_, wk_ = prob.inputs()
                 np.savez("/tmp/cl_in.npz", x0=xk_, omega=wk_, midx=midx, step=-1)
         else:
+            if cost_sets is not None:
+                prob.set_cost(cost_sets[state["k"] % len(cost_sets)])      # this step's prices: mld_problem_set_cost (H2D of 64 x 575 weights + scaling, on the problem's stream)
             prob.select(state["k"] % n_sets)        # next scenario set: device-to-device copy
             state["k"] += 1
         st = prob.solve_resident()                  # K3 + K5/K6 on resident inputs, HIP-event timed inside
@@ -449,7 +631,7 @@ def main():
     def run_steps(count):
         if H == 1:
             return [step() for _ in range(count)]
-        return run_pipelined(probs, count, state, n_sets, gatherer)
+        return run_pipelined(probs, count, state, n_sets, gatherer, cost_sets)
 
     progress("warm-up (%d) and timed steps (%d)" % (args.warmup, args.steps))
     run_steps(args.warmup)
@@ -460,6 +642,19 @@ def main():
     elapsed = time.perf_counter() - t0
     if rd is not None:
         elapsed = rd.all_max(elapsed)
+    # continuity with rounds 1-3, whose timed steps all ran under the 05:00 tariff: two more pipelined steps with that one cost (outside `value`)
+    value_fixed = None
+    if cost_sets is not None and world == 1:
+        for q in probs:
+            q.set_cost(cost)
+        keep_sets, cost_sets = cost_sets, None
+        run_steps(1)
+        sync()
+        t0 = time.perf_counter()
+        run_steps(2)
+        sync()
+        value_fixed = round(world * n_local * 2 / (time.perf_counter() - t0), 2)
+        cost_sets = keep_sets
     # reference: the same kind of step strictly one after another on one handle (clean per-kernel timing for the roofline, latency telemetry)
     sync()
     t0 = time.perf_counter()
@@ -468,6 +663,7 @@ def main():
     elapsed_ref = time.perf_counter() - t0
     if rd is not None:
         elapsed_ref = rd.all_max(elapsed_ref)
+    k_ref_last = (state["k"] - 1) % n_sets      # scenario set of the last reference step (single-instance leg)
     # ---- roofline of the dominant kernel (k_solve) on the LAST timed step: bytes its rank-1 dictionary updates streamed / its HIP-event time
     t0 = time.perf_counter()
     out = prob.download()
@@ -483,7 +679,7 @@ def main():
     io_bytes = 8.0 * n_local * (prob.n + prob.m + d["nx"] + prob.nW)           # SURVEY 8d input/output minimum
     achieved = upd_bytes / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    for name in ("r03_pmc_solve.json", "r02_pmc_solve.json", "r01_pmc_solve.json"):
+    for name in ("r04_pmc_solve.json", "r03_pmc_solve.json", "r02_pmc_solve.json", "r01_pmc_solve.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             try:
@@ -506,6 +702,7 @@ def main():
     with np.errstate(invalid="ignore"):
         gap = np.where(fin, (out["obj"] - out["lower_bound"]) / np.maximum(1e-9, np.abs(out["obj"])), np.nan)
     lim = status == 2
+    PATTERN = pattern_ceiling()
     hist = lambda s: {"optimal": int(s["n_optimal"]), "node_limit": int(s["n_node_limit"]), "infeasible": int(s["n_infeasible"]), "other": int(s["n_numerical"])}
     result = {
         "metric": "MPC steps/sec (whole node) + p50 solve latency, 64-agent microgrid N=24",
@@ -518,11 +715,11 @@ def main():
         "config": {"workload": "BASELINE cfg4 shard: %d agents x %d scenarios per GPU (n_h=7, N_p=24: n=575, 200 binaries, m=500), "
                                "full branch-and-cut MILP, MIPGap=%g, NodeLimit=%d, IterationLimit=%d; every step solves a fresh, independently seeded "
                                "scenario set of the same distribution" % (args.agents, args.scenarios, args.mip_gap, args.node_limit, args.pivot_limit),
-                   "timed_region": "K x (mld_select_inputs [D2D copy of the next staged scenario set] + mld_solve_launch / mld_solve_finish [K3 + K5/K6] (+ RCCL gather of "
+                   "timed_region": "K x (%smld_select_inputs [D2D copy of the next staged scenario set] + mld_solve_launch / mld_solve_finish [K3 + K5/K6] (+ RCCL gather of "
                                    "(obj, status, step-0 inputs) from device buffers when N > 1)), the steps alternating over %d problem handles on their own HIP "
                                    "streams: step k+1 is queued while step k runs, so its workgroups take the CUs the stragglers of step k leave idle (results are "
                                    "bit-identical to one-at-a-time solves); all inputs were staged in HBM before the region, results stay in HBM; the host "
-                                   "download of the full results is outside (download_ms)" % H,
+                                   "download of the full results is outside (download_ms)" % ("" if cost_sets is None else "mld_problem_set_cost [this step's tariff: new q_z / q_mu weights to the device] + ", H),
                    "instances_per_gpu": n_local, "microgrid_steps_per_s": round(world * n_local * args.steps / elapsed / args.agents, 3),
                    "p50_solve_latency_ms": round(float(lat[len(lat) // 2]), 3), "p99_solve_latency_ms": round(float(lat[int(len(lat) * 0.99)]), 3),
                    "status_last_step": {"optimal": int((status == 0).sum()), "infeasible": int((status == 1).sum()), "node_limit": int(lim.sum()),
@@ -553,12 +750,12 @@ def main():
                                  "(see access_pattern for what the memory system delivers when all of them are).  6.3 TB/s is the copy rate the guide measures on "
                                  "this part (MI355X_MICROARCH.md)"}),
                      "access_pattern": {
-                         "ceiling": PATTERN_CEILING_GBS, "unit": "GB/s", "full_rows_ceiling": 6007.0,
+                         "ceiling": PATTERN[0], "unit": "GB/s", "full_rows_ceiling": PATTERN[1], "source": PATTERN[2],
                          "what": "read-modify-write of 38 % of the 64-byte sectors of 107 scattered rows of a private fp64 matrix per iteration, with s_update_rows' lane "
-                                 "layout and loads in flight, on every CU at once and nothing else (scripts/micro/sector_rmw.hip; measured on this part: "
-                                 "profiles/r03_sector_rmw.txt); full_rows_ceiling: the same with every sector active",
+                                 "layout and loads in flight, on every CU at once and nothing else (scripts/micro/sector_rmw.hip; the committed measurement named in `source`, "
+                                 "first 675 MB line); full_rows_ceiling: the same with every sector active",
                          "traffic_rate": (round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None),
-                         "frac": (round(traffic / (kernel_ms * 1e-3) / 1e9 / PATTERN_CEILING_GBS, 4) if traffic else None),
+                         "frac": (round(traffic / (kernel_ms * 1e-3) / 1e9 / PATTERN[0], 4) if (traffic and PATTERN[0]) else None),
                          "note": "HBM bytes by PMC per launch / kernel time, against what the memory system delivers for this access pattern: the kernel keeps it at about "
                                  "two thirds of that ceiling ALL launch long although only a quarter of the workgroups are in the update loop at a time "
                                  "(profiles/r03_resident_workgroups.txt: a workgroup is 40 % slower with 256 resident than with 64) -- the shared memory system, "
@@ -608,6 +805,8 @@ def main():
                             "learnt_over_fifo": round(float(st_nl["solve_ms"]) / kernel_ms, 4),
                             "note": "the last reference step's scenario set solved twice, one launch at a time: with the longest-first order learnt from the previous step "
                                     "(other scenarios of the same agents: agent-level information only) and in plain instance order; learnt_over_fifo > 1 = the learnt order is faster"}
+    if cost_sets is not None:
+        prob.set_cost(cost)         # the legs below use the cost every fixture was generated with
     if args.closed_loop_steps > 0:
         # closed loop: the SAME scenarios advanced step by step (plant update with the inputs just computed, forecast shifted)
         rates, prov = [], []
@@ -642,6 +841,37 @@ def main():
                                          "(x0 in 55..64: most tanks need no heating inside the horizon) towards its steady state and the instances get harder "
                                          "(DESIGN section 6)" % ("" if args.closed_loop_cold else ", the previous plan moved on one step as MIP start "
                                          "(mld_warm_start_from_previous: warm_start=True of controller_base.py:493,509-512)")}
+    if rank == 0 and world == 1 and not args.no_extra_legs:
+        xs_l, ws_l = (x0, om) if k_ref_last == 0 else step_scenarios(rank, k_ref_last, n_local)
+        base_opts = dict(gap_rel=args.mip_gap, max_nodes=args.node_limit, max_pivots=args.pivot_limit)
+        for q in probs[1:]:
+            q.close()
+        progress("single-instance leg")
+        result["single_instance"] = single_instance_leg(agents, N_p, N_t, xs_l, ws_l, midx, tel["latency_ns"], base_opts)
+        prob.close()
+        progress("MIQP leg (cfg3 shape, Q_x = 1e-3 I)")
+        result["miqp"] = miqp_leg()
+        progress("cfg5 leg (128 golden instances, fp32 condensing at the shape)")
+        result["cfg5"] = cfg5_leg()
+    # the driver keeps `config` whole (of other top-level keys only the names): the legs' headline numbers are repeated there
+    cfgd = result["config"]
+    cfgd["value_one_at_a_time"] = result["value_one_at_a_time"]
+    if exact is not None:
+        cfgd["value_exact"] = exact["value_exact"]
+        cfgd["exact_proven_fraction"] = exact["proven_fraction"]
+        cfgd["exact_worst_rel_above_optimum"] = exact.get("worst_rel_above_optimum_all")
+    if "closed_loop" in result:
+        cfgd["closed_loop_value_last_step"] = result["closed_loop"]["value_last_step"]
+        cfgd["closed_loop_proven_last_step"] = result["closed_loop"]["proven_last_step"]
+        cfgd["closed_loop_steps"] = result["closed_loop"]["steps"]
+    for leg in ("single_instance", "miqp", "cfg5"):
+        if result.get(leg) is not None:
+            cfgd[leg] = result[leg]
+    cfgd["cost_update_per_step"] = cost_sets is not None
+    if value_fixed is not None:
+        cfgd["value_fixed_cost"] = value_fixed
+        cfgd["value_fixed_cost_note"] = ("two pipelined steps under the 05:00 tariff of every earlier round's timed region (same scenario distribution): with the clock moving, "
+                                         "later steps see the morning peak earlier in their horizon and cost more pivots per instance (pivots_per_instance)")
     if rank == 0:
         # secondary roofline: condensing K1+K2 (SURVEY 8d formula: outputs + inputs), 64 models per launch
         ms = min(model.condense_device(N_t) for _ in range(5))
@@ -660,7 +890,9 @@ def main():
                                            "speedup_vs_fp64_output": round(ms / ms32, 3)}
         try:        # HBM bytes of the two condensing launches from the same PMC passes (FETCH + WRITE, per launch of each kernel)
             allc = json.load(open(pmc)).get("all", {})
-            kb = sum(allc.get(c, {}).get(k, {}).get("kb_per_launch", 0.0) for c in ("FETCH_SIZE", "WRITE_SIZE") for k in ("k_condense_model", "k_condense_flat"))
+            # (kernel names in the PMC summary are demangled signatures, e.g. "void k_condense_flat<double>(...)": match by substring)
+            kb = sum(v.get("kb_per_launch", 0.0) for c in ("FETCH_SIZE", "WRITE_SIZE") for k, v in allc.get(c, {}).items()
+                     if ("k_condense_model" in k or "k_condense_flat<double>" in k or k.strip() == "k_condense_flat"))
             result["roofline_condense"]["traffic"] = kb * 1024.0 if kb > 0 else None
         except Exception:
             result["roofline_condense"]["traffic"] = None
