@@ -261,6 +261,21 @@ int mld_warm_start_from_previous(mld_problem_t *, int shift);
 int mld_set_cutoffs(mld_problem_t *, const double *cutoff);
 int mld_record_open_nodes(mld_problem_t *, int enable);
 int mld_download_open_nodes(mld_problem_t *, int32_t *depth_out, int16_t *var_out, uint8_t *val_out, uint8_t *flag_out);
+
+/* The same hand-off INSIDE one launch (round 4): what lets ONE solve() call of the reference (controllers/controller_base.py:491-540: one instance
+ * per call, its backend free to use every core on that one tree) use more than one compute unit here, and a batch keep the device busy while its
+ * largest trees finish.  With it enabled the solve kernel's work queue has room for ITEMS behind the instances: an instance (or item) whose complete
+ * depth-first search stops at its node limit publishes the open nodes of its stack as items -- the instance's inputs, the node's fixings, the
+ * search's incumbent as cutoff -- and whichever workgroup runs out of work solves them as instances of their own (max_nodes for an instance,
+ * sub_nodes for an item; a search is split at most max_gen generations deep and only while it has at most max_children open nodes; a tree that
+ * cannot be split further stays MLD_STATUS_NODE_LIMIT with its incumbent and bound).  The results of a tree are merged on the device -- smallest
+ * objective, on ties the node that comes first in the tree -- so mld_download_results returns per instance what an unlimited search of that
+ * instance would have returned; the set of items and every item's arithmetic do not depend on which workgroup ran what, so results are
+ * reproducible.  room_factor: items the queue has room for, as a multiple of the batch (at least 4096; <= 0 keeps the current value, default 2).
+ * Takes effect with the next mld_upload_batch.  Not with a quadratic cost and not on the LDS-resident LP path (those solves run as before).
+ * mld_handoff_stats: out[0] items published by the last solve, out[2] instances that were split and are still unfinished, out[3] room. */
+int mld_set_handoff(mld_problem_t *, int enable, int sub_nodes, int max_gen, int max_children, double room_factor);
+int mld_handoff_stats(mld_problem_t *, int64_t out[4]);
 /* Scenario streaming with everything resident in HBM: the parameter update at the top of the reference's solve() (x_k and
  * omega_tilde set as cvx.Parameter values, controllers/controller_base.py:495-498; the example re-solves with new forecasts every
  * step, micro_grid_control_simulation.py:229-232) for a whole batch.  mld_stage_inputs uploads n_sets input sets of the uploaded

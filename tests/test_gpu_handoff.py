@@ -93,3 +93,59 @@ def test_handoff_on_the_bench_shard_at_the_exact_contract():
     assert proven.sum() >= (plain["status"] == 0).sum()
     assert np.all(out["obj"] <= plain["obj"] + 1e-9 * np.maximum(1.0, np.abs(plain["obj"]))), "the hand-off never ends with a worse incumbent"
     prob.close(); model.close()
+
+
+def test_in_kernel_handoff_with_a_tiny_first_pass_equals_the_unlimited_search():
+    """the same exactness check with the hand-off INSIDE the launch (mld_set_handoff): 3 nodes per instance, 12 per item, items split again up to
+    ten generations deep; the merged result per instance is the exact optimum, and a second run returns the same bits"""
+    wl, ag, m, p = _cfg2(48, gap_rel=0.0, max_nodes=100000, cut_rounds=1)
+    ref = p.solve(ag["x0"], ag["omega"])
+    assert np.all(ref["status"] == 0)
+    out = p.solve_handoff_device(ag["x0"], ag["omega"], first_nodes=3, sub_nodes=12, max_gen=10, max_children=64, room_factor=64.0)
+    print("in-kernel handoff:", out["handoff"], np.unique(out["status"], return_counts=True))
+    assert out["handoff"]["items"] >= 3
+    assert np.all(out["status"] == 0), np.unique(out["status"], return_counts=True)
+    assert np.allclose(out["obj"], ref["obj"], rtol=1e-9, atol=1e-9)
+    assert np.all(out["lower_bound"] <= out["obj"] + 1e-9) and np.all(out["lower_bound"] >= ref["obj"] - 1e-6 * np.maximum(1.0, np.abs(ref["obj"])))
+    d = ag["dims"]
+    sf = cn.standard_form(ag["mats"], ag["atoms"], wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
+    for s in range(48):
+        v = out["v"][s]
+        assert np.all((v[sf["is_bin"]] == 0) | (v[sf["is_bin"]] == 1))
+        h = cn.rhs(sf["evo"], ag["x0"][s], ag["omega"][s])
+        assert np.all(sf["G"] @ v - h <= 1e-6 * np.maximum(1.0, np.abs(sf["G"]).max(axis=1)))
+        q, r = cn.lin_cost(sf["cost"], ag["x0"][s], ag["omega"][s]), cn.cost_const(sf["cost"]["const_terms"], ag["x0"][s], ag["omega"][s])
+        assert abs(q @ v + r - out["obj"][s]) <= 1e-7 * max(1.0, abs(out["obj"][s]))
+    again = p.solve_handoff_device(ag["x0"], ag["omega"], first_nodes=3, sub_nodes=12, max_gen=10, max_children=64, room_factor=64.0)
+    assert np.array_equal(again["obj"], out["obj"]) and np.array_equal(again["v"], out["v"]) and np.array_equal(again["status"], out["status"]), "reproducible whatever the queue order"
+    assert p.opts.max_nodes == 100000
+    plain = p.solve(ag["x0"], ag["omega"])                 # the switch is off again: a plain solve is the plain solve
+    assert np.array_equal(plain["obj"], ref["obj"])
+    p.close(); m.close()
+
+
+def test_in_kernel_handoff_on_the_bench_shard_at_the_exact_contract_and_for_one_instance():
+    """256 bench instances at gap 1e-6 in ONE launch: at least what the one-workgroup-per-instance search proves, every proven objective at the HiGHS
+    optimum; and batch 1 (what MpcController.solve does): the instance's tree spreads over the idle workgroups"""
+    agents, N_p, N_t, x0, om, midx = bench.make_shard(64, 4, 0)
+    d = agents[0]["dims"]
+    model = gpu.GpuModel([a["mats"] for a in agents], d)
+    cost = host.stack_costs([host.cost_from_atoms(a["atoms"], d, N_p, N_t) for a in agents])
+    opt = np.load(os.path.join(GDIR, "solve_cfg4_bench.npz"))["obj"][:256]
+    prob = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=1e-6, max_nodes=20000, max_pivots=400000)
+    plain = prob.solve(x0, om, midx)
+    out = prob.solve_handoff_device(x0, om, midx, first_nodes=300, sub_nodes=200, max_gen=10)
+    print("bench in-kernel handoff:", out["handoff"], "proven plain %d in-kernel %d  kernel ms plain %.0f in-kernel %.0f" %
+          ((plain["status"] == 0).sum(), (out["status"] == 0).sum(), plain["stats"]["solve_ms"], out["stats"]["solve_ms"]))
+    rel = _check_against_optimum(out, opt, 1e-6)
+    proven = out["status"] == 0
+    assert np.abs(rel[proven]).max() <= 2e-6
+    assert proven.sum() >= (plain["status"] == 0).sum() - 1
+    hard = int(np.argmax(plain["nodes"]))
+    one_plain = prob.solve(x0[hard:hard + 1], om[hard:hard + 1], midx[hard:hard + 1])
+    one = prob.solve_handoff_device(x0[hard:hard + 1], om[hard:hard + 1], midx[hard:hard + 1], first_nodes=100, sub_nodes=200, max_gen=10)
+    print("one instance (%d nodes plain): kernel ms plain %.1f in-kernel hand-off %.1f items %d status %d" %
+          (plain["nodes"][hard], one_plain["stats"]["solve_ms"], one["stats"]["solve_ms"], one["handoff"]["items"], one["status"][0]))
+    if one["status"][0] == 0:
+        assert abs(one["obj"][0] - opt[hard]) <= 2e-6 * max(1.0, abs(opt[hard]))
+    prob.close(); model.close()
