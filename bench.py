@@ -292,10 +292,11 @@ def _against_gold(out, k_max, tag="solve_cfg4_bench.npz"):
 
 def exact_leg(prob, x0, om, midx, n_exact, args):
     """north star: "within 1e-6 objective of CPU reference".  The same problem at gap 1e-6 on the first n_exact instances of the shard, objectives
-    checked against the committed HiGHS optima.  `value_exact` is measured WITH sub-tree hand-off (GpuProblem.solve_handoff: a first pass of 300
-    nodes per instance, then the open nodes of the unfinished instances as instances of their own, 200 nodes each, up to 14 rounds, a tree with more
-    than 160 open nodes given up) -- wall clock of the whole procedure, host merging included; `single_pass` is round 2's measurement: one workgroup
-    per instance, NodeLimit 20 000, where one instance running to its limits holds the launch while the other CUs idle."""
+    checked against the committed HiGHS optima.  `value_exact` is measured WITH the in-kernel sub-tree hand-off (GpuProblem.solve_handoff_device: 400
+    nodes per instance, its open nodes as queue entries of the same launch with 200 nodes each, up to 8 generations, a tree with more than 160 open
+    nodes in one generation given up) -- wall clock of upload + launch + download; `single_pass` is round 2's measurement: one workgroup per
+    instance, NodeLimit 20 000, where one instance running to its limits holds the launch while the other CUs idle.  (Round 3 drove the same
+    hand-off from the host, one launch per generation: GpuProblem.solve_handoff, kept for callers that want the rounds.)"""
     n_exact = x0.shape[0] if n_exact < 0 else min(n_exact, x0.shape[0])
     # the longest-first work queue is learnt from the previous solve of the handle, as in the timed region: one untimed pass at the bench's own
     # options over ANOTHER scenario set of the same agents (agent-level information only)
@@ -303,18 +304,18 @@ def exact_leg(prob, x0, om, midx, n_exact, args):
     prob.upload(xs[:n_exact], ws[:n_exact], midx[:n_exact])
     prob.solve_resident()
     prob.set_opts(gap_rel=1e-6, max_nodes=20000, max_pivots=400000)
-    hand = dict(first_nodes=300, sub_nodes=200, rounds=14, max_open=160)      # (scripts/gpu_handoff_probe.py on the final round-3 binary: 5.2 k/s at 99.96 % proven;
-                                                                              #  1000 / 800 / 8: 3.1 k/s at 99.976 %, 600 / 600 / 8: 3.7 k/s, 400 / 400 / 10: 4.6 k/s, 300 / 150 / 16: 5.5 k/s at 99.957 %)
+    hand = dict(first_nodes=400, sub_nodes=200, max_gen=8, max_children=64, max_tree=160, room_factor=3.0)      # (scripts/gpu_handoff_device_probe.py: 5.8 k/s at 99.948 % proven;
+                                                                              #  300 / 200: 5.2 k/s at 99.939 %, 300 / 150: 6.0 k/s at 99.930 %, tree cap 96: 6.7 k/s at 99.911 %)
     t0 = time.perf_counter()
-    out = prob.solve_handoff(x0[:n_exact], om[:n_exact], midx[:n_exact], **hand)
+    out = prob.solve_handoff_device(x0[:n_exact], om[:n_exact], midx[:n_exact], **hand)
     wall = time.perf_counter() - t0
     proven = out["status"] == 0
-    res = dict(gap_rel=1e-6, instances=int(n_exact), value_exact=round(n_exact / wall, 2), unit="agent-solves/s", ms=round(wall * 1e3, 2),
+    res = dict(gap_rel=1e-6, instances=int(n_exact), value_exact=round(n_exact / wall, 2), unit="agent-solves/s", ms=round(wall * 1e3, 2), kernel_ms=round(float(out["stats"]["solve_ms"]), 1),
                proven_fraction=round(float(proven.mean()), 5), nodes_per_instance=round(float(out["nodes"].mean()), 1),
-               pivots_per_instance=round(float(out["pivots"].mean()), 1), method="sub-tree hand-off (mld_download_open_nodes / mld_set_cutoffs)",
-               handoff=dict(hand, first_pass_ms=round(out["handoff"]["first_pass_ms"], 1), handed_off=out["handoff"]["handed_off"],
-                            unfinished=out["handoff"]["unfinished"],
-                            rounds=[dict(sub_instances=r["sub_instances"], kernel_ms=round(r["ms"], 1), trees_left=r.get("parents_left")) for r in out["handoff"]["rounds"]]))
+               pivots_per_instance=round(float(out["pivots"].mean()), 1),
+               method="in-kernel sub-tree hand-off (mld_set_handoff): ONE launch -- searches that stop at their node limit publish their open nodes as entries of the same "
+                      "work queue, idle workgroups solve them, the trees are merged on the device; wall clock of upload + solve + download",
+               handoff=dict(hand, **out["handoff"]))
     if args.agents == 64:
         res.update(_against_gold(out, n_exact))
     # round 2's measurement for continuity: one pass, one workgroup per instance, NodeLimit 20 000 / IterationLimit 400 000
@@ -344,19 +345,18 @@ def exact_leg(prob, x0, om, midx, n_exact, args):
 def handoff_leg(prob, x0, om, midx, args):
     """the bench's own contract (MIPGap / NodeLimit of the timed region) on scenario set 0 with sub-tree hand-off: what the node-limited tail of a
     step becomes when its open nodes are re-queued (quality mode: slower than one pass, nearly everything proven)"""
-    hand = dict(first_nodes=args.node_limit, sub_nodes=max(50, args.node_limit // 2), rounds=4, max_open=64)      # (gpu_handoff_probe.py: 300 / 200 / 8 is 12 % faster at the same proven share, but leaves a reported gap of up to 33 % on the instances it gives up; this setting at most 4.7 %)
+    hand = dict(first_nodes=args.node_limit, sub_nodes=max(50, args.node_limit // 2), max_gen=4, max_children=64, max_tree=64, room_factor=2.0)
     t0 = time.perf_counter()
-    out = prob.solve_handoff(x0, om, midx, **hand)
+    out = prob.solve_handoff_device(x0, om, midx, **hand)
     wall = time.perf_counter() - t0
     fin = np.isfinite(out["obj"])
     lim = out["status"] == 2
     with np.errstate(invalid="ignore"):
         gap = np.where(fin, (out["obj"] - out["lower_bound"]) / np.maximum(1e-9, np.abs(out["obj"])), np.nan)
     res = dict(hand, value=round(x0.shape[0] / wall, 2), unit="agent-solves/s", ms=round(wall * 1e3, 2), proven_fraction=round(float((out["status"] == 0).mean()), 5),
-               node_limited=int(lim.sum()), handed_off=out["handoff"]["handed_off"],
+               node_limited=int(lim.sum()), kernel_ms=round(float(out["stats"]["solve_ms"]), 1), queue=out["handoff"],
                gap_of_limited=({"median": round(float(np.nanmedian(gap[lim])), 5), "max": round(float(np.nanmax(gap[lim])), 5)} if lim.any() else None),
-               rounds=[dict(sub_instances=r["sub_instances"], kernel_ms=round(r["ms"], 1), trees_left=r.get("parents_left")) for r in out["handoff"]["rounds"]],
-               note="wall clock of GpuProblem.solve_handoff on scenario set 0 (inputs uploaded inside, host merging included)")
+               note="wall clock of GpuProblem.solve_handoff_device on scenario set 0 (upload + one launch + download)")
     if args.agents == 64:
         res.update(_against_gold(out, x0.shape[0]))
     return res
@@ -458,22 +458,27 @@ def single_instance_leg(agents, N_p, N_t, x0, om, midx, latency_ns, opts, n_hard
     # batch-1 calls: controllers for the (at most 4) agents that own most of the hardest 1 %
     ag_ids, counts = np.unique(midx[top1], return_counts=True)
     pick = ag_ids[np.argsort(-counts)][:4]
-    lat1, n_calls, worse = [], 0, 0
+    HO = dict(first_nodes=100, sub_nodes=200, max_gen=8, max_children=64, max_tree=160)
+    lat1, lat1h, n_calls, proven1, proven1h = [], [], 0, 0, 0
     for a in pick:
         ag = agents[int(a)]
         d = ag["dims"]
-        ctrl = phc.MpcController(phc.MldModel(ag["mats"], nu_l=d["nu_l"]), N_p=N_p, **opts)
-        ctrl.set_std_obj_atoms(**ag["atoms"])
-        ctrl.build()
         mine = [i for i in top1 if midx[i] == a][:8]
-        ctrl.solve(0, x_k=x0[mine[0]], omega_tilde_k=om[mine[0]], warm_start=False)      # (first call: allocations)
-        for i in mine:
-            t0 = time.perf_counter()
-            ctrl.solve(0, x_k=x0[i], omega_tilde_k=om[i], warm_start=False)
-            lat1.append((time.perf_counter() - t0) * 1e3)
-            n_calls += 1
-        del ctrl
-    lat1 = np.sort(np.array(lat1))
+        for ho in (None, HO):
+            ctrl = phc.MpcController(phc.MldModel(ag["mats"], nu_l=d["nu_l"]), N_p=N_p, handoff=ho, **opts)
+            ctrl.set_std_obj_atoms(**ag["atoms"])
+            ctrl.build()
+            ctrl.solve(0, x_k=x0[mine[0]], omega_tilde_k=om[mine[0]], warm_start=False)      # (first call: allocations)
+            for i in mine:
+                t0 = time.perf_counter()
+                ctrl.solve(0, x_k=x0[i], omega_tilde_k=om[i], warm_start=False)
+                (lat1 if ho is None else lat1h).append((time.perf_counter() - t0) * 1e3)
+                if ho is None:
+                    n_calls += 1; proven1 += ctrl._status == "optimal"
+                else:
+                    proven1h += ctrl._status == "optimal"
+            del ctrl
+    lat1, lat1h = np.sort(np.array(lat1)), np.sort(np.array(lat1h))
     # one batch of the n_hard hardest
     d = agents[0]["dims"]
     model = gpu.GpuModel([a["mats"] for a in agents], d)
@@ -483,11 +488,21 @@ def single_instance_leg(agents, N_p, N_t, x0, om, midx, latency_ns, opts, n_hard
     out = prob.solve(x0[hard], om[hard], midx[hard])
     wall = (time.perf_counter() - t0) * 1e3
     tel = np.sort(prob.telemetry()["latency_ns"]) * 1e-6
-    res = dict(batch_1=dict(calls=n_calls, agents=int(len(pick)), p50_ms=round(float(lat1[len(lat1) // 2]), 2), p99_ms=round(float(lat1[min(len(lat1) - 1, int(len(lat1) * 0.99))]), 2),
-                            max_ms=round(float(lat1[-1]), 2), what="wall time of MpcController.solve(k, x_k, omega_tilde_k) per call, instances drawn from the hardest 1 % of the step"),
+    prob.solve_handoff_device(x0[hard], om[hard], midx[hard], **dict(HO, first_nodes=200))
+    t0 = time.perf_counter()
+    oh = prob.solve_handoff_device(x0[hard], om[hard], midx[hard], **dict(HO, first_nodes=200))
+    wall_h = (time.perf_counter() - t0) * 1e3
+    pq = lambda a, f: round(float(a[min(len(a) - 1, int(len(a) * f))]), 2)
+    res = dict(batch_1=dict(calls=n_calls, agents=int(len(pick)), p50_ms=pq(lat1, 0.5), p99_ms=pq(lat1, 0.99), max_ms=round(float(lat1[-1]), 2), proven=int(proven1),
+                            what="wall time of MpcController.solve(k, x_k, omega_tilde_k) per call, instances drawn from the hardest 1 % of the step: one workgroup per solve"),
+               batch_1_handoff=dict(calls=n_calls, p50_ms=pq(lat1h, 0.5), p99_ms=pq(lat1h, 0.99), max_ms=round(float(lat1h[-1]), 2), proven=int(proven1h), handoff=HO,
+                                    p99_speedup=round(pq(lat1, 0.99) / max(1e-9, pq(lat1h, 0.99)), 2),
+                                    what="the same calls with MpcController(..., handoff=...): the instance's open nodes spread over the idle workgroups of the launch (mld_set_handoff)"),
                batch_64=dict(instances=int(len(hard)), wall_ms=round(wall, 2), p50_ms=round(float(tel[len(tel) // 2]), 2), p99_ms=round(float(tel[min(len(tel) - 1, int(len(tel) * 0.99))]), 2),
                              max_ms=round(float(tel[-1]), 2), proven_fraction=round(float((out["status"] == 0).mean()), 4),
                              what="the %d hardest instances of the step as one batch: wall time of the call and in-kernel latency per instance" % len(hard)),
+               batch_64_handoff=dict(wall_ms=round(wall_h, 2), proven_fraction=round(float((oh["status"] == 0).mean()), 4), queue=oh["handoff"], speedup=round(wall / max(1e-9, wall_h), 2),
+                                     what="the same batch with the in-kernel hand-off (first 200 / sub 200 nodes): the 192 workgroups without an instance take open nodes"),
                in_step_latency_ms=dict(p50=round(float(np.median(latency_ns[hard])) * 1e-6, 2), max=round(float(latency_ns[hard].max()) * 1e-6, 2),
                                        what="the same instances inside the full 32768-instance step (every CU busy)"))
     prob.close(); model.close()
@@ -829,12 +844,11 @@ def main():
         last_handoff = None
         if world == 1:      # the last step's inputs once more with sub-tree hand-off: what the steady state costs when its tail has to be proven too
             xk, wk = prob.inputs()
-            hand = dict(first_nodes=args.node_limit, sub_nodes=max(50, args.node_limit // 2), rounds=4, max_open=64)      # (gpu_handoff_probe.py: 300 / 200 / 8 is 12 % faster at the same proven share, but leaves a reported gap of up to 33 % on the instances it gives up; this setting at most 4.7 %)
+            hand = dict(first_nodes=args.node_limit, sub_nodes=max(50, args.node_limit // 2), max_gen=4, max_children=64, max_tree=64, room_factor=2.0)
             t0 = time.perf_counter()
-            oh = prob.solve_handoff(xk, wk, midx, **hand)
+            oh = prob.solve_handoff_device(xk, wk, midx, **hand)
             t_h = time.perf_counter() - t0
-            last_handoff = dict(hand, value=round(n_local / t_h, 1), proven_fraction=round(float((oh["status"] == 0).mean()), 4), handed_off=oh["handoff"]["handed_off"],
-                                unfinished=oh["handoff"]["unfinished"])
+            last_handoff = dict(hand, value=round(n_local / t_h, 1), proven_fraction=round(float((oh["status"] == 0).mean()), 4), queue=oh["handoff"])
         result["closed_loop"] = {"steps": args.closed_loop_steps, "value_per_step": rates, "proven_per_step": prov, "last_step_with_handoff": last_handoff,
                                  "value_last_step": rates[-1], "proven_last_step": prov[-1], "mip_start": not args.closed_loop_cold,
                                  "note": "mld_advance_batch between solves (reference: sim_step_k -> lsim_k)%s; the population drifts out of the seeded regime "

@@ -273,9 +273,16 @@ int mld_download_open_nodes(mld_problem_t *, int32_t *depth_out, int16_t *var_ou
  * instance would have returned; the set of items and every item's arithmetic do not depend on which workgroup ran what, so results are
  * reproducible.  room_factor: items the queue has room for, as a multiple of the batch (at least 4096; <= 0 keeps the current value, default 2).
  * Takes effect with the next mld_upload_batch.  Not with a quadratic cost and not on the LDS-resident LP path (those solves run as before).
- * mld_handoff_stats: out[0] items published by the last solve, out[2] instances that were split and are still unfinished, out[3] room. */
-int mld_set_handoff(mld_problem_t *, int enable, int sub_nodes, int max_gen, int max_children, double room_factor);
+ * A tree for which more than max_tree items (default 160) of ONE generation have been published keeps growing and is GIVEN UP: its remaining items are skipped and the instance
+ * keeps what its own search returned (MLD_STATUS_NODE_LIMIT, incumbent, bound) -- whether that happens does not depend on the queue order.
+ * mld_handoff_stats: out[0] items published by the last solve, out[1] trees given up for their size, out[2] instances that were split and are
+ * still unfinished (the given-up ones included), out[3] trees given up because the queue was full (raise room_factor: the one order-dependent case). */
+int mld_set_handoff(mld_problem_t *, int enable, int sub_nodes, int max_gen, int max_children, int max_tree, double room_factor);
 int mld_handoff_stats(mld_problem_t *, int64_t out[4]);
+/* How a search that reaches its node limit splits (default 0, 0 = stop and publish everything it leaves open): with donate > 0 it hands off only its
+ * `donate` SHALLOWEST open nodes -- the largest open subtrees -- and goes on below them with another sub_nodes nodes, up to `rounds` times, before it
+ * stops for good: the deep open nodes, which the warm dictionary closes in a few pivots each, stay where they are cheap. */
+int mld_set_handoff_policy(mld_problem_t *, int donate, int rounds);
 /* Scenario streaming with everything resident in HBM: the parameter update at the top of the reference's solve() (x_k and
  * omega_tilde set as cvx.Parameter values, controllers/controller_base.py:495-498; the example re-solves with new forecasts every
  * step, micro_grid_control_simulation.py:229-232) for a whole batch.  mld_stage_inputs uploads n_sets input sets of the uploaded

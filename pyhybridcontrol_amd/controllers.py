@@ -209,6 +209,10 @@ class MpcController(object):
         self._sim_model = model                    # the plant sim_step_k evolves (controller_base.py:235)
         self._model = self._tilde[0] if self._tilde else model
         self._solver_opts = dict(solver_opts)
+        # handoff=dict(first_nodes=..., sub_nodes=..., [max_gen, max_children, max_tree]): the in-kernel sub-tree hand-off (mld_set_handoff) -- the
+        # one instance a solve() call holds spreads over the idle workgroups of the device once its search has run first_nodes nodes (the reference's
+        # backend uses every core of its machine on that one tree, controller_base.py:509).  None / absent = one workgroup per solve.
+        self._handoff = self._solver_opts.pop("handoff", None)
         self._sim_log = MldSimLog()
         self._solve_time_overall = 0
         self._solve_time_solver = 0
@@ -451,6 +455,10 @@ class MpcController(object):
             else:
                 self._epi_dims = dims1
                 self._problem = gpu.GpuProblem(evo.gpu_model(), self._N_p, self._N_tilde, self._signed(cost), **self._solver_opts)
+            if self._handoff:
+                ho = dict(self._handoff)
+                ho.pop("first_nodes", None)
+                self._problem.set_handoff(True, **ho)
         return self._problem
 
     def _x_problem(self, x_k=None):
@@ -541,6 +549,8 @@ class MpcController(object):
             names = dict(MIPGap="gap_rel", NodeLimit="max_nodes", IterationLimit="max_pivots", TimeLimit="time_limit")
             ctor = gpu.make_opts(**self._solver_opts)
             eff = {k2: getattr(ctor, k2) for k2 in ("gap_rel", "max_nodes", "max_pivots", "gap_abs", "time_limit")}
+            if self._handoff and self._handoff.get("first_nodes"):
+                eff["max_nodes"] = int(self._handoff["first_nodes"])      # (with the hand-off the limit is per queue entry: the instance's own search, then sub_nodes per open node)
             eff.update({names[k2]: v2 for k2, v2 in remap.items()})
             cur = self._problem.opts
             if any(getattr(cur, k2) != type(getattr(cur, k2))(v2) for k2, v2 in eff.items()):

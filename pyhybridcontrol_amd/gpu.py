@@ -377,27 +377,28 @@ class GpuProblem(object):
                                                   val.ctypes.data_as(C.POINTER(C.c_uint8)), flag.ctypes.data_as(C.POINTER(C.c_uint8))))
         return depth, var, val, flag
 
-    def set_handoff(self, enable=True, sub_nodes=0, max_gen=8, max_children=64, room_factor=0.0):
+    def set_handoff(self, enable=True, sub_nodes=0, max_gen=8, max_children=64, max_tree=160, room_factor=0.0, donate=0, rounds=0):
         """in-kernel sub-tree hand-off (mld_set_handoff): searches that stop at their node limit publish their open nodes as entries of the same
         launch's work queue; takes effect with the next upload().  sub_nodes 0 = the problem's max_nodes for items too."""
         lib = _lib.load()
-        lib.mld_set_handoff.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
-        check(lib.mld_set_handoff(self._h, 1 if enable else 0, int(sub_nodes), int(max_gen), int(max_children), float(room_factor)))
+        lib.mld_set_handoff.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
+        check(lib.mld_set_handoff(self._h, 1 if enable else 0, int(sub_nodes), int(max_gen), int(max_children), int(max_tree), float(room_factor)))
+        check(lib.mld_set_handoff_policy(self._h, int(donate), int(rounds)))
         self.batch = 0 if not enable else self.batch
 
     def handoff_stats(self):
         out = (C.c_int64 * 4)()
         check(_lib.load().mld_handoff_stats(self._h, out))
-        return dict(items=int(out[0]), unfinished=int(out[2]), room=int(out[3]))
+        return dict(items=int(out[0]), given_up=int(out[1]), unfinished=int(out[2]), queue_full=int(out[3]))
 
-    def solve_handoff_device(self, x0, omega, model_idx=None, fixed_bin=None, first_nodes=None, sub_nodes=None, max_gen=8, max_children=64, room_factor=0.0):
+    def solve_handoff_device(self, x0, omega, model_idx=None, fixed_bin=None, first_nodes=None, sub_nodes=None, max_gen=8, max_children=64, max_tree=160, room_factor=0.0, donate=0, rounds=0):
         """the batch with the hand-off inside ONE launch (set_handoff): upload, solve, download -- the merged results per instance plus `handoff`
         statistics.  The problem's own limits and the hand-off switch are restored afterwards."""
         keep_nodes = int(self.opts.max_nodes)
         try:
             if first_nodes is not None:
                 self.set_opts(max_nodes=int(first_nodes))
-            self.set_handoff(True, sub_nodes=int(sub_nodes or 0), max_gen=max_gen, max_children=max_children, room_factor=room_factor)
+            self.set_handoff(True, sub_nodes=int(sub_nodes or 0), max_gen=max_gen, max_children=max_children, max_tree=max_tree, room_factor=room_factor, donate=donate, rounds=rounds)
             self.upload(x0, omega, model_idx, fixed_bin)
             stats = self.solve_resident()
             out = self.download()

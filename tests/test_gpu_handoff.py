@@ -101,7 +101,7 @@ def test_in_kernel_handoff_with_a_tiny_first_pass_equals_the_unlimited_search():
     wl, ag, m, p = _cfg2(48, gap_rel=0.0, max_nodes=100000, cut_rounds=1)
     ref = p.solve(ag["x0"], ag["omega"])
     assert np.all(ref["status"] == 0)
-    out = p.solve_handoff_device(ag["x0"], ag["omega"], first_nodes=3, sub_nodes=12, max_gen=10, max_children=64, room_factor=64.0)
+    out = p.solve_handoff_device(ag["x0"], ag["omega"], first_nodes=3, sub_nodes=12, max_gen=8, max_children=64, max_tree=100000, room_factor=64.0)
     print("in-kernel handoff:", out["handoff"], np.unique(out["status"], return_counts=True))
     assert out["handoff"]["items"] >= 3
     assert np.all(out["status"] == 0), np.unique(out["status"], return_counts=True)
@@ -116,7 +116,7 @@ def test_in_kernel_handoff_with_a_tiny_first_pass_equals_the_unlimited_search():
         assert np.all(sf["G"] @ v - h <= 1e-6 * np.maximum(1.0, np.abs(sf["G"]).max(axis=1)))
         q, r = cn.lin_cost(sf["cost"], ag["x0"][s], ag["omega"][s]), cn.cost_const(sf["cost"]["const_terms"], ag["x0"][s], ag["omega"][s])
         assert abs(q @ v + r - out["obj"][s]) <= 1e-7 * max(1.0, abs(out["obj"][s]))
-    again = p.solve_handoff_device(ag["x0"], ag["omega"], first_nodes=3, sub_nodes=12, max_gen=10, max_children=64, room_factor=64.0)
+    again = p.solve_handoff_device(ag["x0"], ag["omega"], first_nodes=3, sub_nodes=12, max_gen=8, max_children=64, max_tree=100000, room_factor=64.0)
     assert np.array_equal(again["obj"], out["obj"]) and np.array_equal(again["v"], out["v"]) and np.array_equal(again["status"], out["status"]), "reproducible whatever the queue order"
     assert p.opts.max_nodes == 100000
     plain = p.solve(ag["x0"], ag["omega"])                 # the switch is off again: a plain solve is the plain solve
@@ -134,7 +134,7 @@ def test_in_kernel_handoff_on_the_bench_shard_at_the_exact_contract_and_for_one_
     opt = np.load(os.path.join(GDIR, "solve_cfg4_bench.npz"))["obj"][:256]
     prob = gpu.GpuProblem(model, N_p, N_t, cost, gap_rel=1e-6, max_nodes=20000, max_pivots=400000)
     plain = prob.solve(x0, om, midx)
-    out = prob.solve_handoff_device(x0, om, midx, first_nodes=300, sub_nodes=200, max_gen=10)
+    out = prob.solve_handoff_device(x0, om, midx, first_nodes=300, sub_nodes=200, max_gen=8)
     print("bench in-kernel handoff:", out["handoff"], "proven plain %d in-kernel %d  kernel ms plain %.0f in-kernel %.0f" %
           ((plain["status"] == 0).sum(), (out["status"] == 0).sum(), plain["stats"]["solve_ms"], out["stats"]["solve_ms"]))
     rel = _check_against_optimum(out, opt, 1e-6)
@@ -143,7 +143,7 @@ def test_in_kernel_handoff_on_the_bench_shard_at_the_exact_contract_and_for_one_
     assert proven.sum() >= (plain["status"] == 0).sum() - 1
     hard = int(np.argmax(plain["nodes"]))
     one_plain = prob.solve(x0[hard:hard + 1], om[hard:hard + 1], midx[hard:hard + 1])
-    one = prob.solve_handoff_device(x0[hard:hard + 1], om[hard:hard + 1], midx[hard:hard + 1], first_nodes=100, sub_nodes=200, max_gen=10)
+    one = prob.solve_handoff_device(x0[hard:hard + 1], om[hard:hard + 1], midx[hard:hard + 1], first_nodes=100, sub_nodes=200, max_gen=8)
     print("one instance (%d nodes plain): kernel ms plain %.1f in-kernel hand-off %.1f items %d status %d" %
           (plain["nodes"][hard], one_plain["stats"]["solve_ms"], one["stats"]["solve_ms"], one["handoff"]["items"], one["status"][0]))
     if one["status"][0] == 0:
