@@ -161,6 +161,9 @@ int mld_condense_f32(mld_model_t *, int N_tilde, int flags, float *Phi_x, float 
  * Replaces MpcController.build (controllers/mpc_controller.py:76-101): condensed constraint maps
  * (on device, from the big-M-tightened model), cost pull-back (kernel K4), scaling, bounds
  * (mu >= 0, binaries in {0,1}: controllers/components/variables.py:189-243). */
+/* sizeof(mld_opts) of the library build: bindings check it against their own layout before the first call that takes the struct (the struct has
+ * grown: time_limit in round 3); mld_version() is bumped with every layout change. */
+int mld_opts_size(void);
 int mld_opts_default(mld_opts *);
 int mld_problem_create(mld_problem_t **out, mld_model_t *model, int N_p, int N_tilde, const mld_cost *cost,
                        const mld_opts *opts);
@@ -277,6 +280,11 @@ int mld_download_open_nodes(mld_problem_t *, int32_t *depth_out, int16_t *var_ou
  * keeps what its own search returned (MLD_STATUS_NODE_LIMIT, incumbent, bound) -- whether that happens does not depend on the queue order.
  * mld_handoff_stats: out[0] items published by the last solve, out[1] trees given up for their size, out[2] instances that were split and are
  * still unfinished (the given-up ones included), out[3] trees given up because the queue was full (raise room_factor: the one order-dependent case). */
+/* The reference's build(with_std_constraints=False) and set_constraints(std_evo_constaints=[...]) (controllers/mpc_controller.py:76-101,
+ * controllers/controller_base.py:457-475): with enable = 0 the standard block -- the rows whose right-hand side comes from the batch's own
+ * (x0, omega) -- is not part of the problem; only the blocks of mld_upload_constraint_blocks constrain, and a row none of them covers does not
+ * exist for that solve.  Default 1. */
+int mld_set_std_block(mld_problem_t *, int enable);
 int mld_set_handoff(mld_problem_t *, int enable, int sub_nodes, int max_gen, int max_children, int max_tree, double room_factor);
 int mld_handoff_stats(mld_problem_t *, int64_t out[4]);
 /* How a search that reaches its node limit splits (default 0, 0 = stop and publish everything it leaves open): with donate > 0 it hands off only its

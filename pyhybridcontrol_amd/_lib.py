@@ -49,10 +49,10 @@ _lib = None
 
 # every symbol include/mldgpu.h declares (tests check that the shared object exports all of them)
 EXPORTS = ("mld_device_count", "mld_set_device", "mld_last_error", "mld_version", "mld_device_info",
-           "mld_model_create", "mld_model_create_tv", "mld_model_destroy", "mld_condense_device", "mld_condense", "mld_condense_device_f32", "mld_condense_f32", "mld_opts_default",
+           "mld_opts_size", "mld_model_create", "mld_model_create_tv", "mld_model_destroy", "mld_condense_device", "mld_condense", "mld_condense_device_f32", "mld_condense_f32", "mld_opts_default",
            "mld_problem_create", "mld_problem_set_cost", "mld_problem_destroy", "mld_cost_assemble",
            "mld_solve_batch", "mld_upload_batch", "mld_upload_constraint_blocks", "mld_upload_constraint_blocks_x", "mld_solve_resident", "mld_problem_use_stream", "mld_solve_launch", "mld_solve_finish", "mld_download_results", "mld_download_telemetry",
-           "mld_rhs_batch", "mld_problem_set_opts", "mld_problem_get_opts", "mld_advance_batch", "mld_advance_batch2", "mld_set_warm_start", "mld_warm_start_from_previous", "mld_set_cutoffs", "mld_record_open_nodes", "mld_download_open_nodes", "mld_set_handoff", "mld_handoff_stats", "mld_set_handoff_policy", "mld_download_inputs", "mld_stage_inputs", "mld_select_inputs", "mld_gather_results",
+           "mld_rhs_batch", "mld_problem_set_opts", "mld_problem_get_opts", "mld_advance_batch", "mld_advance_batch2", "mld_set_warm_start", "mld_warm_start_from_previous", "mld_set_cutoffs", "mld_record_open_nodes", "mld_download_open_nodes", "mld_set_handoff", "mld_handoff_stats", "mld_set_handoff_policy", "mld_set_std_block", "mld_download_inputs", "mld_stage_inputs", "mld_select_inputs", "mld_gather_results",
            "mld_comm_unique_id", "mld_comm_init", "mld_gather", "mld_comm_destroy")
 
 
@@ -71,6 +71,9 @@ def load():
         fn = getattr(lib, name)
         if name not in ("mld_last_error", "mld_version"):
             fn.restype = C.c_int
+    if int(lib.mld_opts_size()) != C.sizeof(Opts):
+        raise MldGpuError("libmldgpu.so was built with another layout of mld_opts (%d bytes, this binding %d): rebuild it (python -m pyhybridcontrol_amd.build)"
+                          % (lib.mld_opts_size(), C.sizeof(Opts)))
     _lib = lib
     return lib
 

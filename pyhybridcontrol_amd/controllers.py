@@ -228,6 +228,7 @@ class MpcController(object):
         self._epi_blocks, self._epi_sig, self._epi_dims, self._epi_model, self._vmap = [], (), None, None, None
         self._rate_vars, self._rate_info, self._rate_dims, self._k_neg1 = [], {}, None, {}
         self._sense = 1.0
+        self._std_custom, self._other_objectives = None, []
         self._solution = None
         self._solution_problem, self._k_solved = None, None      # last solution in the GPU problem's layout (the MIP start of the next solve)
         self._x_k = np.zeros((info.nx, 1))
@@ -370,8 +371,17 @@ class MpcController(object):
         """controller_base.py:457-475.  `other_constraints`: blocks from gen_evo_constraints (scenario columns, min / max
         disturbance profiles, reduced N_tilde); they share the standard block's left-hand side, so on the GPU they
         become extra right-hand-side columns reduced by a row-wise minimum (mld_upload_constraint_blocks)."""
-        if std_evo_constaints is not ParNotSet and std_evo_constaints is not None:
-            raise NotImplementedError("custom standard evolution constraints")
+        if std_evo_constaints is not ParNotSet:
+            # None = the standard block (controller_base.py:460-462); a list = those blocks INSTEAD of it -- [] leaves only `other_constraints`
+            # (build(with_std_constraints=False), mpc_controller.py:84-87).  On the GPU: mld_set_std_block(0) + the blocks as right-hand-side columns.
+            if std_evo_constaints is None:
+                self._std_custom = None
+            else:
+                blocks = list(std_evo_constaints)
+                for b in blocks:
+                    if not isinstance(b, EvoConstraint) or b.omega_cols is None:
+                        raise TypeError("std_evo_constaints must come from gen_evo_constraints()")
+                self._std_custom = blocks
         if other_constraints is not ParNotSet:
             blocks = list(other_constraints or [])
             for b in blocks:
@@ -493,11 +503,41 @@ class MpcController(object):
     def _signed(self, cost):
         return {k: (None if v is None else self._sense * np.asarray(v)) for k, v in cost.items()}
 
+    def set_objective(self, std_objective=ParNotSet, other_objectives=ParNotSet):
+        """mpc_controller.py:63-74.  The reference adds cvxpy expressions; here `other_objectives` is a list of further atom sets -- ObjectiveAtoms
+        objects or dicts in the string-keyed form of set_std_obj_atoms -- whose costs are ADDED to the standard objective (linear and quadratic atoms;
+        L1 / Linf / rate atoms belong in the standard set, which carries the model augmentation they need)."""
+        if std_objective is not ParNotSet and std_objective is not None and std_objective != 0:
+            raise NotImplementedError("a custom std_objective expression: set atoms with set_std_obj_atoms() instead")
+        if other_objectives is not ParNotSet:
+            extra = []
+            for oa in (other_objectives or []):
+                if not isinstance(oa, ObjectiveAtoms):
+                    atoms = ObjectiveAtoms(self.mld_info_k.as_gpu_dims(), self._N_p, self._N_tilde)
+                    atoms.set(oa)
+                    oa = atoms
+                if oa.epigraph_blocks() or any(k[3] for k in oa.weights):
+                    raise NotImplementedError("L1 / Linf / rate atoms in other_objectives")
+                extra.append(oa)
+            self._other_objectives = extra
+        self._build_required = True
+
+    @staticmethod
+    def _add_costs(a, b):
+        out = dict(a)
+        for k, v in b.items():
+            if k == "_omega_atoms":
+                out[k] = list(out.get(k, [])) + list(v)
+            elif v is not None:
+                out[k] = v if out.get(k) is None else out[k] + v
+        return out
+
     def build(self, with_std_objective=True, with_std_constraints=True, sense=None, disable_soft_constraints=False):
         """mpc_controller.py:76-101"""
         if not with_std_constraints:
-            raise NotImplementedError("with_std_constraints=False")
-        self.set_constraints(disable_soft_constraints=disable_soft_constraints)
+            self.set_constraints(std_evo_constaints=[], disable_soft_constraints=disable_soft_constraints)
+        else:
+            self.set_constraints(std_evo_constaints=None, disable_soft_constraints=disable_soft_constraints)
         sense = "minimize" if sense is None else sense
         if sense.lower().startswith("min"):
             self._sense = 1.0
@@ -506,8 +546,11 @@ class MpcController(object):
         else:
             raise ValueError("Problem 'sense' must be either 'minimize' or 'maximize', got '%s'." % sense)
         cost = self._std_obj_atoms.to_cost() if with_std_objective else {}
+        for oa in getattr(self, "_other_objectives", []):
+            cost = self._add_costs(cost, oa.to_cost())
         self._omega_atoms = cost.pop("_omega_atoms", []) if cost else []
         self._ensure_problem()
+        self._problem.set_std_block(getattr(self, "_std_custom", None) is None)
         has_norms = any(not b.get("one_sided") for b in self._epi_blocks) or bool(self._rate_vars)
         if has_norms and not with_std_objective:
             raise NotImplementedError("with_std_objective=False while L1 / Linf atoms are set")
@@ -557,15 +600,16 @@ class MpcController(object):
                 self._problem.set_opts(**eff)
             try:
                 cols = rows = xcols = None
-                if getattr(self, "_other_constraints", None):
-                    cols = np.hstack([b.omega_cols for b in self._other_constraints]).T[np.newaxis]
+                all_blocks = list(getattr(self, "_std_custom", None) or []) + list(getattr(self, "_other_constraints", None) or [])
+                if all_blocks:
+                    cols = np.hstack([b.omega_cols for b in all_blocks]).T[np.newaxis]
                     nc = self.mld_info_k.n_constraints
                     nc_p = self._epi_dims["nc"] if self._epi_blocks else nc
-                    rows = np.concatenate([np.full(b.omega_cols.shape[1], (b.rows // nc) * nc_p) for b in self._other_constraints])
-                    if any(not b.x_is_parameter for b in self._other_constraints):
+                    rows = np.concatenate([np.full(b.omega_cols.shape[1], (b.rows // nc) * nc_p) for b in all_blocks])
+                    if any(not b.x_is_parameter for b in all_blocks):
                         xp = self._x_problem().reshape(-1)       # blocks generated with an explicit x_k keep it; the others follow the parameter
                         xcols = np.vstack([np.tile((xp if b.x_is_parameter else b.x_problem), (b.omega_cols.shape[1], 1))
-                                           for b in self._other_constraints])[np.newaxis]
+                                           for b in all_blocks])[np.newaxis]
                 mip_start = None
                 if warm_start and self._solution_problem is not None:
                     shift = 0

@@ -27,7 +27,7 @@ void mld_set_error(const char *fmt, ...)
 extern "C" {
 
 const char *mld_last_error(void) { return g_err; }
-const char *mld_version(void) { return "mldgpu 0.1 (gfx950, fp64 dense-dictionary cut-and-branch)"; }
+const char *mld_version(void) { return "mldgpu 0.4 (gfx950, fp64 dense-dictionary cut-and-branch, in-kernel sub-tree hand-off; sizeof(mld_opts) = 64)"; }
 
 int mld_device_count(void)
 {

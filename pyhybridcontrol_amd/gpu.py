@@ -182,6 +182,7 @@ class GpuProblem(object):
             keep.append(a)
             setattr(c, k, _lib.dptr(a))
         self._keep_cost = keep
+        self._last_cost = dict(quad=tuple(cost.get(k) for k in ("quad_v", "quad_x", "quad_y")))
         return c, keep
 
     def set_cost(self, cost):
@@ -245,14 +246,16 @@ class GpuProblem(object):
         """limits / tolerances of the existing problem (mld_problem_set_opts): MIPGap, NodeLimit, IterationLimit, gap_abs, cut
         rounds, reserved -- no rebuild, like the per-call solver kwargs of the reference's solve()"""
         alias = dict(MIPGap="gap_rel", NodeLimit="max_nodes", IterationLimit="max_pivots", TimeLimit="time_limit")
+        new = _lib.Opts.from_buffer_copy(self.opts)      # a refused call leaves the Python copy as it was, like the device options (ADVICE r3)
         for k, v in opts.items():
             k = alias.get(k, k)
-            if k in ("max_cuts", "n_slots", "presolve") or not hasattr(self.opts, k):
+            if k in ("max_cuts", "n_slots", "presolve") or not hasattr(new, k):
                 raise TypeError("option %r cannot be changed on an existing problem" % k)
             if k == "flags" and int(v) != int(self.opts.flags):
                 raise TypeError("flags (MLD_F32) are fixed when the problem is created")
-            setattr(self.opts, k, type(getattr(self.opts, k))(v))
-        check(_lib.load().mld_problem_set_opts(self._h, C.byref(self.opts)))
+            setattr(new, k, type(getattr(new, k))(v))
+        check(_lib.load().mld_problem_set_opts(self._h, C.byref(new)))
+        self.opts = new
 
     def advance(self):
         """receding horizon on device (mld_advance_batch2): x0 <- plant update with the step-0 slice of the last solution,
@@ -377,6 +380,10 @@ class GpuProblem(object):
                                                   val.ctypes.data_as(C.POINTER(C.c_uint8)), flag.ctypes.data_as(C.POINTER(C.c_uint8))))
         return depth, var, val, flag
 
+    def set_std_block(self, enable=True):
+        """the standard constraint block in or out of the problem (mld_set_std_block): out = only the uploaded constraint blocks constrain"""
+        check(_lib.load().mld_set_std_block(self._h, 1 if enable else 0))
+
     def set_handoff(self, enable=True, sub_nodes=0, max_gen=8, max_children=64, max_tree=160, room_factor=0.0, donate=0, rounds=0):
         """in-kernel sub-tree hand-off (mld_set_handoff): searches that stop at their node limit publish their open nodes as entries of the same
         launch's work queue; takes effect with the next upload().  sub_nodes 0 = the problem's max_nodes for items too."""
@@ -419,6 +426,8 @@ class GpuProblem(object):
         download() (v, obj, status, lower_bound; nodes / pivots summed over all passes) plus `handoff` statistics; the resident batch afterwards
         is the last pass's sub-batch (upload again before advance() / warm starts)."""
         d = self.model.dims
+        if getattr(self, "_keep_cost", None) and any(k is not None for k in (self._last_cost or {}).get("quad", ())):
+            raise MldGpuError("solve_handoff: not with a quadratic cost (a stopped search records its stack only under a linear cost)")
         x0 = _lib.as_f64(x0).reshape(-1, d["nx"]) if d["nx"] else np.zeros((np.shape(omega)[0], 0))
         B = x0.shape[0] if d["nx"] else int(np.asarray(omega).reshape(-1, max(self.nW, 1)).shape[0])
         omega = _lib.as_f64(omega).reshape(B, self.nW) if self.nW else np.zeros((B, 0))
@@ -454,6 +463,7 @@ class GpuProblem(object):
             if sub_opts:                                            # e.g. a shallower root cut loop for the open nodes
                 keep_sub = {k: getattr(self.opts, k) for k in sub_opts}
                 self.set_opts(**sub_opts)
+            stuck_before = set()
             for r in range(int(rounds)):
                 if not open_list:
                     break
@@ -484,10 +494,21 @@ class GpuProblem(object):
                     if ss == 2 and d2[s_] >= 0:
                         new_open.setdefault(i, []).extend((f, nl) for f in expand(fix[s_], d2[s_], v2[s_], l2[s_], f2[s_]))
                     else:
-                        stuck.add(i)                                # a node that could not be split (numerical trouble, no complete search yet): retried as it is
+                        # a node that could not be split (numerical trouble, no complete search yet) is retried ONCE as it is; coming back unsplit a second
+                        # time it stays open for good (the tree ends NODE_LIMIT) instead of being solved again and again with the same budget
+                        key = (i, fix[s_].tobytes())
+                        if key in stuck_before or ss == 4:
+                            dropped = stats.setdefault("dropped", 0)
+                            stats["dropped"] = dropped + 1
+                            gave = stats.setdefault("_gave", set()); gave.add(i)
+                            continue
+                        stuck_before.add(key)
+                        stuck.add(i)
                         new_open.setdefault(i, []).append((fix[s_], nl))
                 for i in list(open_list):
                     tol = max(gap_abs, gap_rel * abs(obj[i])) if np.isfinite(obj[i]) else 0.0
+                    if i in stats.get("_gave", ()) and i not in new_open:
+                        continue                                    # a node of this tree was dropped unsplit: not proven (stays NODE_LIMIT)
                     if i not in new_open:                           # every node closed: proven
                         status[i] = 0 if np.isfinite(obj[i]) else 1
                         lb[i] = min(obj[i], max(lb[i], obj[i] - tol)) if np.isfinite(obj[i]) else lb[i]
@@ -502,7 +523,7 @@ class GpuProblem(object):
                 rstat["parents_left"] = len(open_list)
                 if stuck and all(i in stuck for i in open_list) and r + 1 < rounds:
                     pass                                            # (stuck nodes are simply retried with the next round's budget)
-            stats["unfinished"] = len(open_list) + stats.get("given_up", 0)
+            stats["unfinished"] = len(open_list) + stats.get("given_up", 0) + len(stats.pop("_gave", ()))
             return dict(v=v, obj=obj, status=status, lower_bound=lb, nodes=nodes, pivots=pivots, stats=out["stats"], handoff=stats)
         finally:
             self.record_open_nodes(False)
