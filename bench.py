@@ -93,7 +93,7 @@ def parse():
     ap.add_argument("--handles", type=int, default=2, help="problem handles (each with its own HIP stream and workspace) the timed steps alternate over: "
                     "the workgroups of step k+1 move onto the CUs the stragglers of step k leave idle; 1 = one step after another")
     ap.add_argument("--reference-steps", type=int, default=2, help="steps solved strictly one after another after the timed region (roofline, latency, value_one_at_a_time)")
-    ap.add_argument("--reserved", type=int, default=0, help="diagnostics: opts.reserved bits for the solver (include/mldgpu.h), e.g. 1024 = the experimental LDS-resident branch-and-cut")
+    ap.add_argument("--reserved", type=int, default=0, help="diagnostics: opts.reserved bits for the solver (include/mldgpu.h), e.g. 16384 = no long-step ratio test in the root LP")
     ap.add_argument("--solver-opts", type=str, default="", help="diagnostics: extra solver options, e.g. 'mir_per_round=10,cut_rounds=4'")
     ap.add_argument("--fixed-cost", action="store_true", help="keep one cost for every timed step (round 3) instead of new prices per step (mld_problem_set_cost inside the timed region)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the cfg5 / MIQP / single-instance legs after the timed region")

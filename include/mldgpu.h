@@ -79,17 +79,17 @@ typedef struct {
                               bit6 first-fractional branching instead of penalty branching, bit7 K3 / K4 on the vector ALUs (k_rhs, k_gemm)
                               instead of the matrix cores, bit8 relaxation-only batches (every binary fixed) on the dense-dictionary kernel instead of
                               the LDS-resident revised simplex (k_lp_lds), bit9 k_lp_lds with a working-basis capacity of 24 (its overflow fall-back to the
-                              dense kernel then takes most instances; the same cap applies to k_milp_lds),
-                              bit10 EXPERIMENTAL: mixed-integer batches (linear cost, time-invariant models that fit) on the LDS-resident branch-and-cut
-                              k_milp_lds (csrc/milp_lds.inc) instead of the dense-dictionary kernel; instances it cannot finish are
-                              re-solved by the dense kernel in the same call, bit11 leave those instances at status -1 instead (counting only),
-                              bit12 k_milp_lds profile slots = phases inside the simplex (mld_debug_profile), bit13 no anti-stalling cost
+                              dense kernel then takes most instances), bit11 leave those instances at status -1 instead (counting only),
+                              (bits 10 and 12 belonged to the LDS-resident branch-and-cut experiment of rounds 2-3, removed in round 4: DESIGN section 4c),
+                              bit13 no anti-stalling cost
                               perturbation in the dual simplex (A/B of round 3's change), bit14 no long-step (bound flipping) ratio test in the root LP (A/B). */
     double time_limit;     /* seconds per INSTANCE on the device clock (Gurobi TimeLimit; the reference passes TimeLimit=20 with every solve,
                               examples/residential_mg_with_pv_and_dewhs/micro_grid_control_simulation.py:232, forwarded by
                               controllers/controller_base.py:509-512): the branch-and-bound of an instance ends once it has run that long, like
                               max_nodes ends it -- status MLD_STATUS_NODE_LIMIT with the incumbent and the proven bound (an instance without an
-                              incumbent still gets its one rescue dive).  0 (default) = no limit. */
+                              incumbent still gets its one rescue dive).  The clock is read between nodes, between cut rounds and every 128 pivots inside
+                              an LP, so ONE instance ends within its limit plus a few pivots; the limit is per instance, not per call: a batch larger than
+                              the number of resident workgroups takes (instances / workgroups) x time_limit at worst.  0 (default) = no limit. */
 } mld_opts;
 
 /* Linear cost in tiled horizon form (the Python layer parses the reference's string-keyed atoms,

@@ -40,6 +40,9 @@
 #define ORC_CUT_PATIENCE 10     /* cut rounds without progress of the bound before the cut loop gives up (round 3: was 2; csrc/problem.inc S_CUT_PATIENCE).
                                 * Paired runs, 2048 bench + 256 steady-state instances, patience 2 -> 10: row updates -12 % / -1 %, per-instance geometric mean -3 % on both,
                                 * node-limited 5 -> 1 and 10 -> 5; environment ORC_PATIENCE overrides (study) */
+#ifndef ORC_PSC_DEFAULT
+#define ORC_PSC_DEFAULT 0      /* pseudocost branching: 0 off, k >= 1 = a direction's pseudocost is used once it has k observations (environment ORC_PSC) */
+#endif
 #ifndef ORC_BFRT_DEFAULT
 #define ORC_BFRT_DEFAULT 1     /* long-step (bound flipping) dual ratio test: 0 off, 1 root LP only (csrc/problem.inc), 2 + cut rounds, 3 everywhere; environment ORC_BFRT overrides (study) */
 #endif
@@ -1487,6 +1490,12 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
         int *fx_j = (int *)calloc(nb + 1, sizeof(int));
         double T = have ? INFINITY : root_bound + fmax(1e-7 * fmax(1.0, fabs(root_bound)), gtol(o, root_bound));
         const int pen_mode = getenv("ORC_PEN") ? atoi(getenv("ORC_PEN")) : ORC_PEN_DEFAULT;   /* 0: first fractional binary in index order (A/B) */
+        /* pseudocosts (Benichou et al. 1971; reliability threshold of Achterberg, Koch, Martin 2005 with the Driebeek-Tomlin penalty as the unreliable
+         * estimate): per binary and direction the average rise of the LP value per unit of change, learnt from every child LP of this search */
+        const int psc_mode = getenv("ORC_PSC") ? atoi(getenv("ORC_PSC")) : ORC_PSC_DEFAULT;
+        double *ps_sum = dalloc(2 * (size_t)n + 2); int *ps_cnt = (int *)calloc(2 * (size_t)n + 2, sizeof(int));
+        double *stk_obj = dalloc(nb + 2), *stk_x = dalloc(nb + 2);
+        int fresh_child = 0;          /* the node about to be evaluated is the child just created on top of the stack */
         double lbg = root_bound;      /* proven global lower bound: raised by every exhaustive pass */
         status = ORC_NODE_LIMIT;
         for (;;) {
@@ -1516,6 +1525,16 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
                 const double cut = fmin(T, inc_cut);
                 double node_obj = INFINITY;
                 lp = dual_simplex(t, cut + 1e-12);
+                if (psc_mode && fresh_child && depth > 0 && (lp == LP_OPTIMAL || lp == LP_CUTOFF || lp == LP_INFEASIBLE)) {
+                    const int jb = stk_j[depth - 1];
+                    const int up = t->lo[jb] > 0.5;
+                    const double dist = up ? 1.0 - stk_x[depth - 1] : stk_x[depth - 1];
+                    double child = lp == LP_INFEASIBLE ? INFINITY : objective(t);
+                    if (lp != LP_OPTIMAL && child < cut) child = cut;          /* (a cut-off child rose at least to the cutoff) */
+                    if (!(child < 1e300)) child = fmax(cut < 1e300 ? cut : stk_obj[depth - 1], stk_obj[depth - 1]) + fabs(stk_obj[depth - 1]) * 0.1 + 1e-3;
+                    if (dist > 1e-9 && stk_obj[depth - 1] < 1e300) { ps_sum[2 * jb + up] += fmax(0.0, child - stk_obj[depth - 1]) / dist; ps_cnt[2 * jb + up]++; }
+                }
+                fresh_child = 0;
                 if (getenv("ORC_DEBUG")) fprintf(stderr, "node %d ph %d depth %d lp=%d obj=%.12g cut=%.12g T=%.12g pivots=%ld\n", nodes, phase, depth, lp, objective(t), cut, T, t->pivots);
                 if (lp == LP_ITERLIMIT) limit = 1;
                 else if (lp == LP_OPTIMAL || lp == LP_CUTOFF) {
@@ -1584,6 +1603,11 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
                                     continue;
                                 }
                                 if (bforced) continue;
+                                if (psc_mode) {     /* reliable pseudocosts replace the penalty (a lower bound from ONE dual ratio test, usually far too small) */
+                                    const double f = xs[j] - floor(xs[j]);
+                                    if (ps_cnt[2 * j] >= psc_mode) pd = fmax(pd, ps_sum[2 * j] / ps_cnt[2 * j] * f);
+                                    if (ps_cnt[2 * j + 1] >= psc_mode) pu = fmax(pu, ps_sum[2 * j + 1] / ps_cnt[2 * j + 1] * (1.0 - f));
+                                }
                                 const double sc = fmax(fmin(pd, 1e30), eps) * fmax(fmin(pu, 1e30), eps);
                                 if (sc > bscore) { bscore = sc; branch_j = j; branch_x = xs[j]; force_first = (pd == pu) ? -1 : (pd < pu ? 0 : 1); second_done = 0; }
                             }
@@ -1639,8 +1663,9 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
                 if (branch_j >= 0 && !limit && !finished && !dive_end) {
                     double first = force_first >= 0 ? (double)force_first : (branch_x >= 0.5 ? 1.0 : 0.0);
                     if (have && phase == PH_FINAL && !second_done) first = x_out[branch_j];     /* guided (Danna et al. 2005): towards the incumbent first */
-                    stk_j[depth] = branch_j; stk_first[depth] = first; stk_second[depth] = (unsigned char)second_done; depth++;
+                    stk_j[depth] = branch_j; stk_first[depth] = first; stk_second[depth] = (unsigned char)second_done; stk_obj[depth] = node_obj; stk_x[depth] = branch_x; depth++;
                     set_bounds(t, branch_j, first, first);
+                    fresh_child = 1;
                     continue; /* evaluate the child */
                 }
                 /* ---- backtrack */
@@ -1648,7 +1673,7 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
                 while (depth > 0 && stk_second[depth - 1]) { depth--; set_bounds(t, stk_j[depth], root_lo[stk_j[depth]], root_hi[stk_j[depth]]); }
                 if (depth == 0) break;
                 stk_second[depth - 1] = 1;
-                { const int j = stk_j[depth - 1]; const double v = 1.0 - stk_first[depth - 1]; set_bounds(t, j, v, v); }
+                { const int j = stk_j[depth - 1]; const double v = 1.0 - stk_first[depth - 1]; set_bounds(t, j, v, v); fresh_child = 1; }
             }
             st->phase_work[2 + phase_at_pass] += t->work - work_at_pass;
             if (phase == PH_RINS) {   /* release the fixings */
