@@ -82,13 +82,15 @@ typedef struct {
                               dense kernel then takes most instances), bit11 leave those instances at status -1 instead (counting only),
                               (bits 10 and 12 belonged to the LDS-resident branch-and-cut experiment of rounds 2-3, removed in round 4: DESIGN section 4c),
                               bit13 no anti-stalling cost
-                              perturbation in the dual simplex (A/B of round 3's change), bit14 no long-step (bound flipping) ratio test in the root LP (A/B). */
+                              perturbation in the dual simplex (A/B of round 3's change), bit14 no long-step (bound flipping) ratio test in the root LP (A/B),
+                              bit17 a MIP start is evaluated lazily (round 3: only when the deepening passes end without an incumbent) instead of right after the root LP (A/B). */
     double time_limit;     /* seconds per INSTANCE on the device clock (Gurobi TimeLimit; the reference passes TimeLimit=20 with every solve,
                               examples/residential_mg_with_pv_and_dewhs/micro_grid_control_simulation.py:232, forwarded by
                               controllers/controller_base.py:509-512): the branch-and-bound of an instance ends once it has run that long, like
                               max_nodes ends it -- status MLD_STATUS_NODE_LIMIT with the incumbent and the proven bound (an instance without an
-                              incumbent still gets its one rescue dive).  The clock is read between nodes, between cut rounds and every 128 pivots inside
-                              an LP, so ONE instance ends within its limit plus a few pivots; the limit is per instance, not per call: a batch larger than
+                              incumbent still gets its one rescue dive).  The clock is read between nodes, between cut rounds and, once the search has started,
+                              every 128 pivots inside an LP (the root LP always runs to its end -- without it there is no answer --, and so does the rescue
+                              dive), so ONE instance ends within its limit plus its root LP and a few pivots; the limit is per instance, not per call: a batch larger than
                               the number of resident workgroups takes (instances / workgroups) x time_limit at worst.  0 (default) = no limit. */
 } mld_opts;
 
@@ -241,9 +243,10 @@ int mld_advance_batch2(mld_problem_t *, int32_t *n_skipped_out);
 /* MIP start of the resident batch (the reference calls its backend with warm_start=True, controllers/controller_base.py:493,509-512: the
  * previous values of the variables are the solver's start).  bin_start: batch x n_bin bytes, the values (0 / 1) of the binaries in the order of
  * the variable layout (step-major, controllers/components/variables.py:189-243); an instance whose first byte is 255 has no start; NULL
- * clears the start.  The start is used lazily: an instance whose first search passes find no incumbent evaluates it (binaries fixed, one LP)
- * in place of its dive; a feasible start becomes the incumbent and the search continues around it.  Any upload / selection of new inputs
- * clears the start. */
+ * clears the start.  The start is evaluated right after the root LP (binaries fixed, one LP, verified against the original rows): a feasible
+ * start becomes the incumbent, the cut loop stops as soon as the bound is within the gap of it, and the search -- if one is still needed --
+ * starts around it (RINS, then the guided depth-first search).  (Round 3 evaluated it only when the first passes ended without an incumbent:
+ * opts.reserved bit 17.)  Any upload / selection of new inputs clears the start. */
 int mld_set_warm_start(mld_problem_t *, const uint8_t *bin_start);
 /* The start built on the device from the last solution of the resident batch: shift = 0 takes the plan as it is (what warm_start=True means
  * to the reference's backend: the variables' previous values), shift = k > 0 moves it k steps towards the present and repeats its last step

@@ -40,6 +40,9 @@
 #define ORC_CUT_PATIENCE 10     /* cut rounds without progress of the bound before the cut loop gives up (round 3: was 2; csrc/problem.inc S_CUT_PATIENCE).
                                 * Paired runs, 2048 bench + 256 steady-state instances, patience 2 -> 10: row updates -12 % / -1 %, per-instance geometric mean -3 % on both,
                                 * node-limited 5 -> 1 and 10 -> 5; environment ORC_PATIENCE overrides (study) */
+#ifndef ORC_EAGER_START
+#define ORC_EAGER_START 1      /* a MIP start is evaluated right after the root LP (1, round 4) or only when the deepening passes end without an incumbent (0, round 3) */
+#endif
 #ifndef ORC_PSC_DEFAULT
 #define ORC_PSC_DEFAULT 0      /* pseudocost branching: 0 off, k >= 1 = a direction's pseudocost is used once it has k observations (environment ORC_PSC) */
 #endif
@@ -1403,7 +1406,7 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
     double *stk_first = dalloc(nb + 2);
     unsigned char *stk_second = (unsigned char *)calloc(nb + 2, 1);
     int *sv_j = (int *)calloc(nb + 2, sizeof(int)); double *sv_lo = dalloc(nb + 2), *sv_hi = dalloc(nb + 2);
-    int lp = LP_OPTIMAL, root_ok = 0, unbounded = 0, started = 0;
+    int lp = LP_OPTIMAL, root_ok = 0, unbounded = 0, started = 0, nodes_pre = 0;
     leaf_ctx L = { n, m, nb, bins, Pq, q, G, h, lb, ub, sv_j, sv_lo, sv_hi, xo, &best, &have, x_out, &unbounded };
     st->nodes = 1;
     /* root LP + cut rounds; if the LP breaks down while cutting the root is rebuilt and solved without cuts */
@@ -1424,6 +1427,15 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
         st->phase_work[0] = t->work;
         root_ok = 1;
         st->cuts = 0;
+        if (x_start && !started && !t->P && ORC_EAGER_START) {
+            /* MIP start, evaluated right after the root LP (round 4, csrc/problem.inc: same rule): the cut loop below stops as soon as the bound is within
+             * the gap of it -- in a closed loop the shifted plan is near-optimal and three quarters of the instances need no search at all */
+            started = 1;
+            nodes_pre = 1;
+            leaf_eval(t, &L, x_start);
+            lp = dual_simplex(t, INFINITY);
+            if (lp != LP_OPTIMAL) { root_ok = 0; status = ORC_NUMERICAL; goto done; }
+        }
         if (use_cuts) {
             int stalled = 0;
             const long saved_cap = t->max_pivots;
@@ -1441,6 +1453,7 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
                 lp = dual_simplex(t, INFINITY);
                 t->max_pivots = saved_cap;
                 if (lp != LP_OPTIMAL) { root_ok = 0; break; }
+                if (have && best - gtol(o, best) <= objective(t)) break;      /* (eager start: nothing left to prove) */
                 if (objective(t) - before < 1e-6 * fmax(1.0, fabs(before))) { if (++stalled >= (getenv("ORC_PATIENCE") ? atoi(getenv("ORC_PATIENCE")) : ORC_CUT_PATIENCE)) break; } else stalled = 0;
             }
             /* cut rows whose slack still sits basic in its own row (the cut never had to leave) and is clearly positive when the cut loop ends
@@ -1481,13 +1494,20 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
          * the plain search continues with the incumbent as cutoff for the rest of the node budget. */
         enum { PH_IDS = 0, PH_DIVE, PH_RINS, PH_FINAL };
         const double root_bound = st->root_bound;
-        int nodes = 0, limit = 0, pass = 0, rescue = 0, node_budget = o->max_nodes;
-        int phase = PH_IDS, rins_rounds = 0, nfix = 0;
+        int nodes = nodes_pre, limit = 0, pass = 0, rescue = 0, node_budget = o->max_nodes;
+        int phase = have ? PH_RINS : PH_IDS, rins_rounds = 0, nfix = 0, xroot_set = 0;      /* (an incumbent from an eager start: RINS around it first) */
+        if (have) node_budget = o->max_nodes / 4 < o->max_nodes ? o->max_nodes / 4 : o->max_nodes;
         int ids_cap = o->max_nodes / 8 > 16 ? o->max_nodes / 8 : 16;
         if (getenv("ORC_IDS_CAP")) { const int c = atoi(getenv("ORC_IDS_CAP")); if (c < ids_cap) ids_cap = c; }
         const double dive_tol = 1e-2 * fmax(1.0, fabs(root_bound));
         double *xroot = dalloc(nb + 1), *fx_lo = dalloc(nb + 1), *fx_hi = dalloc(nb + 1);
         int *fx_j = (int *)calloc(nb + 1, sizeof(int));
+        if (have) {      /* (the first pass is RINS: it needs the root relaxation's binaries now) */
+            for (int c = 0; c < n; ++c) if (t->nonbasic[c] < n) xs[t->nonbasic[c]] = t->xN[c];
+            for (int r = 0; r < t->m; ++r) if (t->basic[r] < n) xs[t->basic[r]] = t->xB[r];
+            for (int k = 0; k < nb; ++k) xroot[k] = xs[bins[k]];
+            xroot_set = 1;
+        }
         double T = have ? INFINITY : root_bound + fmax(1e-7 * fmax(1.0, fabs(root_bound)), gtol(o, root_bound));
         const int pen_mode = getenv("ORC_PEN") ? atoi(getenv("ORC_PEN")) : ORC_PEN_DEFAULT;   /* 0: first fractional binary in index order (A/B) */
         /* pseudocosts (Benichou et al. 1971; reliability threshold of Achterberg, Koch, Martin 2005 with the Driebeek-Tomlin penalty as the unreliable
@@ -1554,7 +1574,7 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
                         for (int c = 0; c < n; ++c) if (t->nonbasic[c] < n) xs[t->nonbasic[c]] = t->xN[c];
                         for (int r = 0; r < t->m; ++r) if (t->basic[r] < n) xs[t->basic[r]] = t->xB[r];
                         }
-                        if (nodes == 1) for (int k = 0; k < nb; ++k) xroot[k] = xs[bins[k]];
+                        if (!xroot_set) { for (int k = 0; k < nb; ++k) xroot[k] = xs[bins[k]]; xroot_set = 1; }
                         if (depth == 0 && have && (phase == PH_IDS || phase == PH_FINAL) && !t->P) {
                             /* reduced-cost fixing at the true root (no temporary fixings active): a non-basic binary whose
                              * reduced cost exceeds the room below the cutoff cannot leave its bound in any solution that

@@ -236,14 +236,21 @@ def test_mip_start_never_changes_the_proven_optimum():
         assert r["status"] == "optimal" and abs(r["obj"] - ref["obj"]) <= 1e-9 * max(1.0, abs(ref["obj"]))
 
 
-def test_mip_start_is_evaluated_lazily():
-    """an instance the deepening passes close by themselves never pays for the start (identical pivots); on one that reaches the
-    dive, a good start is taken as the incumbent"""
+def test_mip_start_is_evaluated_after_the_root_lp():
+    """round 4: a MIP start is evaluated right after the root LP (one leaf), and the cut loop stops once the bound is within the gap of it.  A poor start
+    (all binaries 0) costs that leaf and changes nothing else about the answer; the optimal point as start ends the solve at the root with fewer pivots
+    than the cold solve of an instance that needs a tree"""
     sf, q, h, _ = _bench_instance(98)              # proven at the root
     kw = dict(gap_rel=1e-2, max_nodes=800, presolve=0, max_pivots=40000)
     a = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], **kw)
     b = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], x_start=np.zeros(q.size), **kw)
-    assert a["nodes"] <= 2 and b["pivots"] == a["pivots"] and b["obj"] == a["obj"]
+    assert a["nodes"] <= 2 and a["status"] == b["status"] == "optimal"
+    assert abs(b["obj"] - a["obj"]) <= 1e-2 * abs(a["obj"]) + 1e-9 and b["lower_bound"] <= a["obj"] + 1e-9
+    sf, q, h, _ = _bench_instance(1907)            # needs cuts and a search when solved cold
+    cold = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], **kw)
+    warm = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], x_start=cold["x"], **kw)
+    assert warm["status"] == "optimal" and warm["obj"] <= cold["obj"] + 1e-9 * abs(cold["obj"])
+    assert warm["nodes"] <= cold["nodes"] + 1
 
 
 def test_cost_perturbation_breaks_the_stall_and_keeps_the_value():
