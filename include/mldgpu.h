@@ -83,7 +83,7 @@ typedef struct {
                               (bits 10 and 12 belonged to the LDS-resident branch-and-cut experiment of rounds 2-3, removed in round 4: DESIGN section 4c),
                               bit13 no anti-stalling cost
                               perturbation in the dual simplex (A/B of round 3's change), bit14 no long-step (bound flipping) ratio test in the root LP (A/B),
-                              bit17 a MIP start is evaluated lazily (round 3: only when the deepening passes end without an incumbent) instead of right after the root LP (A/B). */
+                              bit17 a MIP start is evaluated lazily (round 3: only when the deepening passes end without an incumbent) instead of before the root LP (A/B). */
     double time_limit;     /* seconds per INSTANCE on the device clock (Gurobi TimeLimit; the reference passes TimeLimit=20 with every solve,
                               examples/residential_mg_with_pv_and_dewhs/micro_grid_control_simulation.py:232, forwarded by
                               controllers/controller_base.py:509-512): the branch-and-bound of an instance ends once it has run that long, like
@@ -243,9 +243,9 @@ int mld_advance_batch2(mld_problem_t *, int32_t *n_skipped_out);
 /* MIP start of the resident batch (the reference calls its backend with warm_start=True, controllers/controller_base.py:493,509-512: the
  * previous values of the variables are the solver's start).  bin_start: batch x n_bin bytes, the values (0 / 1) of the binaries in the order of
  * the variable layout (step-major, controllers/components/variables.py:189-243); an instance whose first byte is 255 has no start; NULL
- * clears the start.  The start is evaluated right after the root LP (binaries fixed, one LP, verified against the original rows): a feasible
- * start becomes the incumbent, the cut loop stops as soon as the bound is within the gap of it, and the search -- if one is still needed --
- * starts around it (RINS, then the guided depth-first search).  (Round 3 evaluated it only when the first passes ended without an incumbent:
+ * clears the start.  The start is evaluated FIRST (binaries fixed, one LP from the slack basis, verified against the original rows; the root
+ * relaxation is then solved from that leaf's basis): a feasible start becomes the incumbent, the cut loop stops as soon as the bound is within
+ * the gap of it, and the search -- if one is still needed -- starts around it (RINS, then the guided depth-first search).  (Round 3 evaluated it only when the first passes ended without an incumbent:
  * opts.reserved bit 17.)  Any upload / selection of new inputs clears the start. */
 int mld_set_warm_start(mld_problem_t *, const uint8_t *bin_start);
 /* The start built on the device from the last solution of the resident batch: shift = 0 takes the plan as it is (what warm_start=True means

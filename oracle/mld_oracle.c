@@ -41,7 +41,7 @@
                                 * Paired runs, 2048 bench + 256 steady-state instances, patience 2 -> 10: row updates -12 % / -1 %, per-instance geometric mean -3 % on both,
                                 * node-limited 5 -> 1 and 10 -> 5; environment ORC_PATIENCE overrides (study) */
 #ifndef ORC_EAGER_START
-#define ORC_EAGER_START 1      /* a MIP start is evaluated right after the root LP (1, round 4) or only when the deepening passes end without an incumbent (0, round 3) */
+#define ORC_EAGER_START 1      /* a MIP start is evaluated BEFORE the root LP (1, round 4) or only when the deepening passes end without an incumbent (0, round 3) */
 #endif
 #ifndef ORC_PSC_DEFAULT
 #define ORC_PSC_DEFAULT 0      /* pseudocost branching: 0 off, k >= 1 = a direction's pseudocost is used once it has k observations (environment ORC_PSC) */
@@ -1419,6 +1419,13 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
             for (int c = 0; c < n; ++c) place(t, c);
             refresh(t);
         }
+        if (x_start && !started && !t->P && ORC_EAGER_START) {
+            /* the MIP start FIRST (round 4, csrc/problem.inc: same rule): its leaf LP from the slack basis, then the root relaxation from the leaf's
+             * basis; the incumbent is known before the first cut, and the cut loop below stops as soon as the bound is within the gap of it */
+            started = 1;
+            nodes_pre = 1;
+            leaf_eval(t, &L, x_start);
+        }
         { const int bm = getenv("ORC_BFRT") ? atoi(getenv("ORC_BFRT")) : ORC_BFRT_DEFAULT; t->bfrt_on = bm >= 1;
         lp = dual_simplex(t, INFINITY);
         t->bfrt_on = bm >= 2; }
@@ -1427,15 +1434,6 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
         st->phase_work[0] = t->work;
         root_ok = 1;
         st->cuts = 0;
-        if (x_start && !started && !t->P && ORC_EAGER_START) {
-            /* MIP start, evaluated right after the root LP (round 4, csrc/problem.inc: same rule): the cut loop below stops as soon as the bound is within
-             * the gap of it -- in a closed loop the shifted plan is near-optimal and three quarters of the instances need no search at all */
-            started = 1;
-            nodes_pre = 1;
-            leaf_eval(t, &L, x_start);
-            lp = dual_simplex(t, INFINITY);
-            if (lp != LP_OPTIMAL) { root_ok = 0; status = ORC_NUMERICAL; goto done; }
-        }
         if (use_cuts) {
             int stalled = 0;
             const long saved_cap = t->max_pivots;

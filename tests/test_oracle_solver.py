@@ -236,8 +236,8 @@ def test_mip_start_never_changes_the_proven_optimum():
         assert r["status"] == "optimal" and abs(r["obj"] - ref["obj"]) <= 1e-9 * max(1.0, abs(ref["obj"]))
 
 
-def test_mip_start_is_evaluated_after_the_root_lp():
-    """round 4: a MIP start is evaluated right after the root LP (one leaf), and the cut loop stops once the bound is within the gap of it.  A poor start
+def test_mip_start_is_evaluated_first():
+    """round 4: a MIP start is evaluated FIRST (its leaf LP from the slack basis, the root relaxation from there), and the cut loop stops once the bound is within the gap of it.  A poor start
     (all binaries 0) costs that leaf and changes nothing else about the answer; the optimal point as start ends the solve at the root with fewer pivots
     than the cold solve of an instance that needs a tree"""
     sf, q, h, _ = _bench_instance(98)              # proven at the root
