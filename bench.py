@@ -420,9 +420,10 @@ def cfg5_leg():
     return res
 
 
-def miqp_leg(n_inst=512):
+def miqp_leg(n_inst=4096):
     """The quadratic-cost path (north star: 'batched MIQP'): BASELINE cfg3 shape with the MIQP variant's Q_x = 1e-3 I, same MIPGap /
-    NodeLimit as the timed region, next to the MILP of the same instances."""
+    NodeLimit as the timed region, next to the MILP of the same instances.  4 096 instances = 16 per resident workgroup: with the 512 of the first version
+    of this leg a launch was as long as its slowest instance (two instances per workgroup; 232 solves/s), which says nothing about the path."""
     from pyhybridcontrol_amd import gpu, host, synthetic as syn
     res = {}
     for quad in (False, True):
