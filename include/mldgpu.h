@@ -62,7 +62,8 @@ typedef struct {
 typedef struct {
     double gap_abs;        /* absolute optimality tolerance (default 1e-9) */
     double gap_rel;        /* relative MIP gap (Gurobi MIPGap; default 0 = prove optimality) */
-    int32_t max_nodes;     /* per instance (default 100000) */
+    int32_t max_nodes;     /* per instance (default 100000): nodes of the branch-and-bound tree(s) a search evaluates -- the look-ahead LPs of the dive, the
+                              leaf evaluations and a MIP start are not nodes (round 4; rounds 1-3 counted every LP, which is not Gurobi's NodeLimit) */
     int32_t max_pivots;    /* per instance simplex iteration limit (default 50000) */
     int32_t cut_rounds;    /* cut rounds at the root (default -1 = max(10, min(30, binaries / 40)); 0 = no cuts) */
     int32_t cuts_per_round;/* Gomory cuts per round (default -1 = max(80, binaries / 5)) */

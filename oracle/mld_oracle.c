@@ -1423,8 +1423,7 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
             /* the MIP start FIRST (round 4, csrc/problem.inc: same rule): its leaf LP from the slack basis, then the root relaxation from the leaf's
              * basis; the incumbent is known before the first cut, and the cut loop below stops as soon as the bound is within the gap of it */
             started = 1;
-            nodes_pre = 1;
-            leaf_eval(t, &L, x_start);
+            leaf_eval(t, &L, x_start);                  /* (a leaf, not a node of the tree: not counted) */
         }
         { const int bm = getenv("ORC_BFRT") ? atoi(getenv("ORC_BFRT")) : ORC_BFRT_DEFAULT; t->bfrt_on = bm >= 1;
         lp = dual_simplex(t, INFINITY);
@@ -1658,15 +1657,13 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
                     if (branch_j < 0) dive_end = 1;
                     else {
                         const double tgt = 1.0;
-                        set_bounds(t, branch_j, tgt, tgt);
-                        nodes++;
+                        set_bounds(t, branch_j, tgt, tgt);          /* (look-ahead LPs are not nodes of the tree: not counted against NodeLimit, round 4) */
                         int la = dual_simplex(t, INFINITY);
                         const double oa = la == LP_OPTIMAL ? objective(t) : INFINITY;
                         double take = tgt;
                         if (la == LP_ITERLIMIT) limit = 1;
                         else if (!(oa <= node_obj + dive_tol)) {
                             set_bounds(t, branch_j, 1.0 - tgt, 1.0 - tgt);
-                            nodes++;
                             const int lb2 = dual_simplex(t, INFINITY);
                             const double ob2 = lb2 == LP_OPTIMAL ? objective(t) : INFINITY;
                             if (lb2 == LP_ITERLIMIT) limit = 1;
@@ -1704,7 +1701,6 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
                 /* MIP start, evaluated lazily: only an instance whose deepening passes found no incumbent pays for it (one leaf); a feasible
                  * start then takes the place of the dive and the search continues with RINS around it */
                 started = 1;
-                nodes++;
                 leaf_eval(t, &L, x_start);
                 if (have) { phase = PH_RINS; limit = 0; T = INFINITY; node_budget = nodes + o->max_nodes / 4 < o->max_nodes ? nodes + o->max_nodes / 4 : o->max_nodes; continue; }
             }
