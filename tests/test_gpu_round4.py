@@ -94,3 +94,43 @@ def test_handle_state_after_advance_and_failed_set_opts():
     st = p.download()
     assert np.all(st["nodes"] <= 200 + 3 * p.n_bin + 12), "the failed call must not have installed its node limit on the device"
     p.close(); m.close()
+
+
+def test_cfg2_relaxation_only_at_its_stated_batch_of_256():
+    """BASELINE configs[1] as stated: single agent, N = 24, batch 256, QP-relaxation kernel only (binaries fixed).  The LDS-resident revised simplex
+    (k_lp_lds) against the dense-dictionary kernel on all 256 instances and against the C oracle's LP on every eighth one; and the same batch with
+    the MIQP variant's quadratic cost (dense kernel, simplicial decomposition) against the oracle's QP on every 32nd."""
+    from oracle import condense_np as cn, orc, tighten_np
+    from test_gpu_loop import _fixed_pattern
+    nb = 256
+    for quad in (False, True):
+        wl = syn.make_workload("cfg2", batch=nb, quadratic=quad)
+        ag = wl["agents"][0]
+        d = ag["dims"]
+        m = gpu.GpuModel([ag["mats"]], d)
+        cost = host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"])
+        p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost)
+        fixed = _fixed_pattern(ag, wl, p, d, np.random.Generator(np.random.PCG64(11)), nb)
+        a = p.solve(ag["x0"], ag["omega"], fixed_bin=fixed)
+        assert np.all(a["nodes"] == 1)
+        ok = a["status"] == 0
+        assert ok.sum() >= nb // 2
+        if not quad:
+            q = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost, reserved=256)          # the dense-dictionary kernel on the same LPs
+            b = q.solve(ag["x0"], ag["omega"], fixed_bin=fixed)
+            assert np.array_equal(a["status"], b["status"])
+            assert np.all(np.abs(a["obj"][ok] - b["obj"][ok]) <= 1e-9 * np.maximum(1.0, np.abs(b["obj"][ok])))
+            q.close()
+        sf = cn.standard_form(tighten_np.tighten(ag["mats"], d, nu_l=d["nu_l"]), ag["atoms"], wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
+        bins = np.where(sf["is_bin"])[0]
+        for s in range(0, nb, 32 if quad else 8):
+            lb, ub = sf["lb"].copy(), sf["ub"].copy()
+            lb[bins] = ub[bins] = fixed[s]
+            h, qv, r = cn.rhs(sf["evo"], ag["x0"][s], ag["omega"][s]), cn.lin_cost(sf["cost"], ag["x0"][s], ag["omega"][s]), cn.cost_const(sf["cost"]["const_terms"], ag["x0"][s], ag["omega"][s])
+            isb0 = np.zeros_like(sf["is_bin"])
+            ref = (orc.solve_miqp(sf["cost"]["P"], qv, sf["G"], h, lb, ub, isb0, max_nodes=10, presolve=0) if quad
+                   else orc.solve_milp(qv, sf["G"], h, lb, ub, isb0, max_nodes=10, presolve=0))
+            assert (ref["status"] == "optimal") == bool(ok[s]), (quad, s, ref["status"], a["status"][s])
+            if ok[s]:
+                assert abs(a["obj"][s] - (ref["obj"] + r)) <= 1e-6 * max(1.0, abs(ref["obj"] + r)), (quad, s, a["obj"][s], ref["obj"] + r)
+        p.close(); m.close()
