@@ -60,7 +60,7 @@ def test_bench_workload_within_gap_of_highs_optimum():
     print("bench parity: proven %.4f within-gap %.4f worst %.4f node-limited %d" % (proven, within, rel.max(), int((out["status"] == 2).sum())))
     assert proven >= 0.995, proven                      # (measured 0.9990; round 2: 0.9941, round 1: 0.979 at NodeLimit 400)
     assert within >= 0.997, within
-    assert rel.max() <= 0.06, "an incumbent more than 6 %% above the optimum: %g" % rel.max()      # (measured 0.027; round 2: 0.099)
+    assert rel.max() <= 0.03, "an incumbent more than 3 %% above the optimum: %g" % rel.max()      # (VERDICT r3's bar; measured 0.027 over rounds 3-4; round 2: 0.099)
     wl = dict(N_p=N_p, N_tilde=N_t)
     for i in list(range(0, 1024, 37)) + list(np.where(out["status"] == 2)[0][:8]):      # certificates on the original rows
         ag = dict(agents[int(midx[i])], x0=x0[i][None], omega=om[i][None])
@@ -128,4 +128,4 @@ def test_cfg5_shape_against_highs_at_size():
     assert np.all(obj[ok][claimed] - hi[claimed] <= 1e-2 * np.abs(obj[ok][claimed]) + 1e-6 * scale[claimed]), "OPTIMAL outside the gap of HiGHS's incumbent"
     rel = (obj[ok] - hi) / scale
     print("cfg5: proven %d of %d, within 1 %% of HiGHS's incumbent %d of %d, worst %.3f" % ((st == 0).sum(), nb, (rel <= 1e-2).sum(), ok.sum(), rel.max()))
-    assert (st == 0).mean() >= 0.40                     # (52-59 % over the binaries of round 3; round 2: 41-46 %)
+    assert (st == 0).mean() >= 0.50                     # (round 4: 59 %, 76 of 128, with NodeLimit counting tree nodes only; 52-59 % over the binaries of round 3; round 2: 41-46 %.  Not adequate: DESIGN section 9)
