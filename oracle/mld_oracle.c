@@ -257,6 +257,7 @@ typedef struct {
     double *Gx, *hx;    /* scaled original rows + cuts: mcap x n, mcap */
     double *q, *rs, *cs;
     double *lo, *hi;    /* ntot */
+    double *clo, *chi;  /* n: bounds the CUT builders and the dead-row test may use for the continuous structurals (implied bounds of the presolve; == lo / hi without it) */
     double *xB, *xN;
     int *basic, *nonbasic, *where; /* where[id] = column index if nonbasic else -1-row */
     unsigned char *at_upper, *is_int, *skip;
@@ -307,6 +308,67 @@ static void equilibrate(const double *G, int m, int n, const unsigned char *is_i
     free(cmax);
 }
 
+/* Per-instance presolve (opts.presolve bit 2; csrc/problem.inc s_presolve runs the same passes): row-activity bound propagation with integer
+ * rounding (Savelsbergh 1994, section 3.2) on the SCALED rows of this instance -- the right-hand side carries the instance's x0 and omega, so a
+ * bound that no per-model tightening can know follows here (the grid power of a step lies between omega_k and omega_k + sum P_i: z_k, free in the
+ * model, gets finite bounds; a step whose omega_k decides the sign fixes its delta_k).  Jacobi passes: every pass reads the bounds of the pass
+ * before (row statistics first, then every column takes the tightest bound its rows imply), so the result does not depend on the order rows are
+ * visited in -- a thread per row / per column on the GPU computes the same numbers.  The implied bounds of the CONTINUOUS structurals go to
+ * clo / chi only: the LP keeps its own (a free z stays free and basic -- making the implied bounds LP bounds doubles the dictionary's fill and
+ * was measured slower), the c-MIR builder substitutes them (a row with a free continuous entry was unusable before) and the dead-row test adds
+ * them up.  Binaries the propagation fixes are fixed in the LP.  Returns 0 when the rows are infeasible under the bounds. */
+#define ORC_PRE_PASSES 8
+static int presolve_instance(dict_t *t, int m0)
+{
+    const int n = t->n;
+    double *tot = dalloc(m0), *nlo = dalloc(n), *nhi = dalloc(n);
+    int *meta = (int *)calloc(m0 + 1, sizeof(int));      /* -1: every term finite, >= 0: the one column with an infinite term, -2: more than one */
+    int ok = 1;
+    for (int pass = 0; pass < ORC_PRE_PASSES && ok; ++pass) {
+        for (int i = 0; i < m0; ++i) {
+            const double *g = t->Gx + (size_t)i * n;
+            double s = 0.0; int ninf = 0, jinf = -1;
+            for (int j = 0; j < n; ++j) {
+                if (g[j] == 0.0) continue;
+                const double b = g[j] > 0.0 ? t->clo[j] : t->chi[j];
+                if (fabs(b) >= 0.5 * ORC_BIG) { ninf++; jinf = j; } else s += g[j] * b;
+            }
+            tot[i] = s; meta[i] = ninf == 0 ? -1 : (ninf == 1 ? jinf : -2);
+            if (t->hx[i] < 1.0e29 && ninf == 0 && s > t->hx[i] + 1e-6 * fmax(1.0, fabs(t->hx[i]))) ok = 0;
+        }
+        if (!ok) break;
+        int changed = 0;
+        for (int j = 0; j < n; ++j) {
+            double lo = t->clo[j], hi = t->chi[j];
+            const double lo0 = lo, hi0 = hi;
+            for (int i = 0; i < m0; ++i) {
+                const double gj = t->Gx[(size_t)i * n + j];
+                if (gj == 0.0 || t->hx[i] >= 1.0e29) continue;
+                const int mt = meta[i];
+                if (mt == -2 || (mt >= 0 && mt != j)) continue;
+                const double rest = mt == j ? tot[i] : tot[i] - gj * (gj > 0.0 ? lo0 : hi0);
+                double b = (t->hx[i] - rest) / gj;
+                if (gj > 0.0) {
+                    if (t->is_int[j]) b = floor(b + 1e-6);
+                    if (b < hi - 1e-9 * fmax(1.0, fabs(b))) hi = b;
+                } else {
+                    if (t->is_int[j]) b = ceil(b - 1e-6);
+                    if (b > lo + 1e-9 * fmax(1.0, fabs(b))) lo = b;
+                }
+            }
+            if (lo > hi + 1e-6 * fmax(1.0, fabs(lo))) ok = 0;
+            if (hi < lo) { if (hi0 == hi) lo = hi; else hi = lo; }      /* (round-off: the bound that moved gives way) */
+            if (lo != lo0 || hi != hi0) changed = 1;
+            nlo[j] = lo; nhi[j] = hi;
+        }
+        memcpy(t->clo, nlo, sizeof(double) * n); memcpy(t->chi, nhi, sizeof(double) * n);
+        if (!changed) break;
+    }
+    if (ok) for (int j = 0; j < n; ++j) if (t->is_int[j]) { t->lo[j] = t->clo[j]; t->hi[j] = t->chi[j]; }
+    free(tot); free(nlo); free(nhi); free(meta);
+    return ok;
+}
+
 /* Rows that cannot bind under the ROOT bounds (largest activity <= right-hand side): their slack is basic in the slack basis,
  * never violates its bound and so never leaves; nothing reads such a row again (cuts substitute rows of basic STRUCTURALS,
  * verification goes to the original rows), so the pivots need not maintain it: bit 1 of skip[].  Bounds only tighten below
@@ -321,8 +383,8 @@ static void mark_dead(dict_t *t, int m0, int enable)
         double act = 0.0; int inf = 0;
         for (int j = 0; j < n; ++j) {
             const double gj = g[j];
-            if (gj > 0.0) { if (t->hi[j] < 0.5 * ORC_BIG) act += gj * t->hi[j]; else inf = 1; }
-            else if (gj < 0.0) { if (t->lo[j] > -0.5 * ORC_BIG) act += gj * t->lo[j]; else inf = 1; }
+            if (gj > 0.0) { if (t->chi[j] < 0.5 * ORC_BIG) act += gj * t->chi[j]; else inf = 1; }
+            else if (gj < 0.0) { if (t->clo[j] > -0.5 * ORC_BIG) act += gj * t->clo[j]; else inf = 1; }
         }
         if (!inf && act <= t->hx[i] - 1e-7) t->skip[i] = 2;
     }
@@ -1131,7 +1193,7 @@ static double mir_build(const dict_t *t, int i, double delta, const double *x, d
     for (int j = 0; j < n; ++j) {
         const double gj = g[j];
         if (gj == 0.0) continue;
-        const double lo = t->lo[j], hi = t->hi[j];
+        const double lo = t->is_int[j] ? t->lo[j] : t->clo[j], hi = t->is_int[j] ? t->hi[j] : t->chi[j];
         if (t->is_int[j]) { if (lo == hi) rhs -= gj * lo; else if (x[j] > 0.5) rhs -= gj; }
         else {
             const int lof = lo > -0.5 * ORC_BIG, hif = hi < 0.5 * ORC_BIG;
@@ -1149,7 +1211,7 @@ static double mir_build(const dict_t *t, int i, double delta, const double *x, d
     for (int j = 0; j < n; ++j) {
         const double gj = g[j];
         if (gj == 0.0) continue;
-        const double lo = t->lo[j], hi = t->hi[j];
+        const double lo = t->is_int[j] ? t->lo[j] : t->clo[j], hi = t->is_int[j] ? t->hi[j] : t->chi[j];
         if (t->is_int[j]) {
             if (lo == hi) continue;
             const int comp = x[j] > 0.5;
@@ -1352,14 +1414,14 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
     double *lb = dalloc(n), *ub = dalloc(n);
     memcpy(lb, lb_in, sizeof(double) * n); memcpy(ub, ub_in, sizeof(double) * n);
     int status = ORC_INFEASIBLE;
-    if (o->presolve && !propagate_bounds(G, h, m, n, lb, ub, is_bin)) { st->status = status; free(lb); free(ub); return status; }
+    if ((o->presolve & 1) && !propagate_bounds(G, h, m, n, lb, ub, is_bin)) { st->status = status; free(lb); free(ub); return status; }
     dict_t T; dict_t *t = &T; memset(t, 0, sizeof(T));
     t->n = n; t->m0 = m; t->m = m; t->mcap = m + o->max_cuts; t->ld = n + 1; t->ntot = n + t->mcap;
     t->max_pivots = o->max_pivots > 0 ? o->max_pivots : 2000000000L;
     t->D = dalloc((size_t)(t->mcap + 1) * t->ld);
     t->Gx = dalloc((size_t)t->mcap * n); t->hx = dalloc(t->mcap);
     t->q = dalloc(n); t->rs = dalloc(m); t->cs = dalloc(n);
-    t->lo = dalloc(t->ntot); t->hi = dalloc(t->ntot);
+    t->lo = dalloc(t->ntot); t->hi = dalloc(t->ntot); t->clo = dalloc(n); t->chi = dalloc(n);
     t->xB = dalloc(t->mcap); t->xN = dalloc(n);
     t->basic = (int *)calloc(t->mcap + 1, sizeof(int)); t->nonbasic = (int *)calloc(n + 1, sizeof(int));
     t->where = (int *)calloc(t->ntot + 1, sizeof(int));
@@ -1372,7 +1434,7 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
         for (int j = 0; j < n; ++j) t->Gx[(size_t)i * n + j] = G[(size_t)i * n + j] * t->rs[i] * t->cs[j];
         t->hx[i] = h[i] * t->rs[i];
     }
-    for (int j = 0; j < n; ++j) { t->q[j] = q[j] * t->cs[j]; t->lo[j] = lb[j] / t->cs[j]; t->hi[j] = ub[j] / t->cs[j]; }
+    for (int j = 0; j < n; ++j) { t->q[j] = q[j] * t->cs[j]; t->lo[j] = lb[j] / t->cs[j]; t->hi[j] = ub[j] / t->cs[j]; t->clo[j] = t->lo[j]; t->chi[j] = t->hi[j]; }
     double *Ps = NULL;
     if (Pq) {
         Ps = dalloc((size_t)n * n);
@@ -1392,6 +1454,7 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
             t->partner[j] = (cnt == 1 && v < 0.0 && !is_bin[j] && lb[j] == 0.0 && ub[j] == INFINITY && q[j] >= 0.0) ? row : -1;
         }
     }
+    const int pre_infeasible = (o->presolve & 4) && !presolve_instance(t, m);
     mark_dead(t, m, Pq == NULL);
     reset_dictionary(t);
     for (int c = 0; c < n; ++c) place(t, c);
@@ -1409,6 +1472,7 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
     int lp = LP_OPTIMAL, root_ok = 0, unbounded = 0, started = 0, nodes_pre = 0;
     leaf_ctx L = { n, m, nb, bins, Pq, q, G, h, lb, ub, sv_j, sv_lo, sv_hi, xo, &best, &have, x_out, &unbounded };
     st->nodes = 1;
+    if (pre_infeasible) { status = ORC_INFEASIBLE; goto done; }
     /* root LP + cut rounds; if the LP breaks down while cutting the root is rebuilt and solved without cuts */
     for (int attempt = 0; attempt < 2 && !root_ok; ++attempt) {
         const int use_cuts = attempt == 0 && o->cut_rounds > 0;
@@ -1749,7 +1813,7 @@ done:
     if (Ps) { free(Ps); free(t->Y); free(t->PY); free(t->Hm); free(t->cm); free(t->wm); free(t->gcost); free(t->vcur); free(t->Pv); }
     st->pivots = (int)t->pivots; st->refactors = t->refactors; st->status = status; st->work = t->work; st->bland = t->bland; st->flips = t->flips;
     *obj_out = have ? best : INFINITY;
-    free(lb); free(ub); free(t->D); free(t->Gx); free(t->hx); free(t->q); free(t->rs); free(t->cs); free(t->lo);
+    free(lb); free(ub); free(t->clo); free(t->chi); free(t->D); free(t->Gx); free(t->hx); free(t->q); free(t->rs); free(t->cs); free(t->lo);
     free(t->hi); free(t->xB); free(t->xN); free(t->basic); free(t->nonbasic); free(t->where); free(t->at_upper);
     free(t->is_int); free(t->skip); free(t->tmp_col); free(t->tmp_row); free(t->dw); free(t->partner); free(bins); free(root_lo); free(root_hi);
     free(xs); free(xo); free(stk_j); free(stk_first); free(stk_second); free(sv_j); free(sv_lo); free(sv_hi);
