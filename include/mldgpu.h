@@ -68,7 +68,12 @@ typedef struct {
     int32_t cut_rounds;    /* cut rounds at the root (default -1 = max(10, min(30, binaries / 40)); 0 = no cuts) */
     int32_t cuts_per_round;/* Gomory cuts per round (default -1 = max(80, binaries / 5)) */
     int32_t max_cuts;      /* rows reserved for cuts (default -1 = max(300, rows / 4) up to 400 binaries, rows / 2 above; 0 = no cuts) */
-    int32_t presolve;      /* bit1: per-model probing-based big-M tightening (default 2); bit0 reserved */
+    int32_t presolve;      /* default 6.  bit1: per-model probing-based big-M tightening (once, when the problem is created).  bit2 (round 4): per-INSTANCE
+                              presolve before the root LP -- row-activity bound propagation with integer rounding on the instance's own right-hand side
+                              (its x0 / omega); binaries it fixes are fixed, the implied bounds of the continuous variables are used by the rounding cuts
+                              and by the test for rows that can never bind, the LP keeps the model's bounds; an instance whose rows are infeasible under
+                              the bounds returns MLD_STATUS_INFEASIBLE without a pivot.  What a MIP backend's own presolve does for the
+                              reference (controller_base.py:497-512 hands the instance to the solver as is).  bit0 reserved */
     int32_t n_slots;       /* solver slots = persistent workgroups (0 = auto: what is resident at once, one per CU) */
     int32_t mir_per_round; /* complemented mixed-integer rounding cuts on the original rows per cut round
                               (default -1 = 20 up to 400 binaries, binaries / 5 above; 0 = off) */
@@ -81,7 +86,8 @@ typedef struct {
                               instead of the matrix cores, bit8 relaxation-only batches (every binary fixed) on the dense-dictionary kernel instead of
                               the LDS-resident revised simplex (k_lp_lds), bit9 k_lp_lds with a working-basis capacity of 24 (its overflow fall-back to the
                               dense kernel then takes most instances), bit11 leave those instances at status -1 instead (counting only),
-                              (bits 10 and 12 belonged to the LDS-resident branch-and-cut experiment of rounds 2-3, removed in round 4: DESIGN section 4c),
+                              (bit 10 belonged to the LDS-resident branch-and-cut experiment of rounds 2-3, removed in round 4: DESIGN section 4c), bit12 no per-instance presolve
+                              (A/B of presolve bit2 on the same problem handle),
                               bit13 no anti-stalling cost
                               perturbation in the dual simplex (A/B of round 3's change), bit14 no long-step (bound flipping) ratio test in the root LP (A/B),
                               bit17 a MIP start is evaluated lazily (round 3: only when the deepening passes end without an incumbent) instead of before the root LP (A/B). */
