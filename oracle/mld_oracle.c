@@ -1241,6 +1241,7 @@ static int mir_round(dict_t *t, int max_cuts)
     int nc = 0;
     static const double divs[4] = {1.0, 2.0, 4.0, 8.0};
     for (int i = 0; i < m0; ++i) {
+        if (t->skip[i] & 2) continue;      /* a row that cannot bind under the bounds has no rounding that cuts a point inside them (csrc/problem.inc: same screen) */
         const double *g = t->Gx + (size_t)i * n;
         double best = 0.0, bdelta = 0.0;
         for (int j = 0; j < n; ++j) {
