@@ -848,6 +848,10 @@ static int primal_simplex(dict_t *t)
         if (t->pivots >= t->max_pivots) return LP_ITERLIMIT;
         const double cur = objective(t);
         if (cur < last_obj - 1e-12 * fmax(1.0, fabs(cur))) { stall = 0; last_obj = cur; } else stall++;
+        /* cycling (round 4): Bland's rule on the entering side with Harris' ratio test is no guarantee, and this routine has no refactorisation of its own -- a
+         * QP relaxation's return to the LP(q) vertex burnt 40 000 pivots at one objective value on a dictionary grown to 1e13 after a pivot of 1e-6.  The
+         * caller re-derives the dictionary and goes on with the LP bound of the node (sd_relax) */
+        if (stall > 2 * (n + m) + 500) return LP_ITERLIMIT;
         const int bland = stall > 30;
         int c = -1; double best = ORC_DTOL; int bid = 0x7fffffff;
         for (int k = 0; k < n; ++k) {
@@ -1002,7 +1006,7 @@ static int sd_relax(dict_t *t, double cutoff, double *lb_out, double *fv_out)
         for (int j = 0; j < n; ++j) { g[j] = Pv[j] + t->q[j]; fv += v[j] * (0.5 * Pv[j] + t->q[j]); gv += g[j] * v[j]; }
         reprice(t, g);
         const int lp = primal_simplex(t);
-        if (lp != LP_OPTIMAL) { rc = -1; break; }
+        if (lp != LP_OPTIMAL) { rc = -2; break; }
         t->qp_iters++;
         double *ynew = Y + (size_t)p * n;
         if (p >= SD_PMAX) {   /* drop the lightest vertex */
@@ -1048,8 +1052,13 @@ static int sd_relax(dict_t *t, double cutoff, double *lb_out, double *fv_out)
         p = k2;
         for (int j = 0; j < n; ++j) { double a = 0, b = 0; for (int i = 0; i < p; ++i) { a += w[i] * Y[(size_t)i * n + j]; b += w[i] * PY[(size_t)i * n + j]; } v[j] = a; Pv[j] = b; }
     }
-    reprice(t, t->q);
-    if (primal_simplex(t) != LP_OPTIMAL) rc = -1;
+    if (rc != -2) { reprice(t, t->q); if (primal_simplex(t) != LP_OPTIMAL) rc = -2; }
+    if (rc == -2) {
+        /* the primal simplex gave up (cycling on a dictionary that has lost its accuracy): re-derive the dictionary from the original rows and return to the
+         * LP(q) vertex of the node with the dual simplex; the caller goes on with the LP bound and the LP point of this node (-2), or ends (-1) */
+        refactor(t);
+        if (dual_simplex(t, INFINITY) != LP_OPTIMAL) rc = -1;
+    }
     *lb_out = LB; *fv_out = fv;
     return rc;
 }
@@ -1528,8 +1537,9 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
     if (!root_ok) { status = ORC_NUMERICAL; goto done; }
     if (t->P) {   /* root bound of the QP relaxation */
         double lbq, fvq;
-        if (sd_relax(t, INFINITY, &lbq, &fvq) < 0) { status = ORC_NUMERICAL; goto done; }
-        st->root_bound = lbq;
+        const int rcq = sd_relax(t, INFINITY, &lbq, &fvq);
+        if (rcq == -1) { status = ORC_NUMERICAL; goto done; }
+        st->root_bound = rcq == -2 ? objective(t) : lbq;      /* (-2: the QP relaxation could not be finished -- the LP(q) value is a bound too) */
     } else
     st->root_bound = objective(t);
     if (getenv("ORC_DUMP_ROOT")) {   /* study only: the root point after cuts (unscaled), one value per line */
@@ -1621,17 +1631,18 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
                 if (lp == LP_ITERLIMIT) limit = 1;
                 else if (lp == LP_OPTIMAL || lp == LP_CUTOFF) {
                     double obj = objective(t);       /* LP(q) value: a valid bound also when P is PSD */
-                    int pruned = (lp == LP_CUTOFF || obj > cut);
+                    int pruned = (lp == LP_CUTOFF || obj > cut), qp_lp = 0;
                     node_obj = obj;
                     if (!pruned && t->P) {
                         double lbq, fvq;
                         const int rc = sd_relax(t, cut, &lbq, &fvq);
-                        if (rc < 0) { limit = 1; pruned = 1; obj = INFINITY; }
+                        if (rc == -1) { limit = 1; pruned = 1; obj = INFINITY; }
+                        else if (rc == -2) qp_lp = 1;      /* the QP relaxation could not be finished: this node goes on with its LP(q) bound and LP point */
                         else { obj = lbq; pruned = (rc == 1 || obj > cut); }
                     }
                     if (pruned) { if (obj <= inc_cut && obj < t_next) t_next = obj; }
                     else {
-                        if (t->P) memcpy(xs, t->vcur, sizeof(double) * n);
+                        if (t->P && !qp_lp) memcpy(xs, t->vcur, sizeof(double) * n);
                         else {
                         for (int c = 0; c < n; ++c) if (t->nonbasic[c] < n) xs[t->nonbasic[c]] = t->xN[c];
                         for (int r = 0; r < t->m; ++r) if (t->basic[r] < n) xs[t->basic[r]] = t->xB[r];
@@ -1656,7 +1667,10 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
                             double bv = -1.0;
                             for (int k = 0; k < nb; ++k) {
                                 const int j = bins[k];
-                                if (fabs(xs[j] - rint(xs[j])) > ORC_INTTOL && xs[j] > bv) { bv = xs[j]; branch_j = j; branch_x = xs[j]; }
+                                /* a FIXED binary is never a candidate (round 4): basic with lo == hi it can drift off its value by more than the integrality tolerance
+                                 * while the primal simplex of a QP relaxation ignores its tiny column entries; picked again and again it made a dive of 700 levels
+                                 * on a 200-binary instance and the stack arrays overflowed (found under AddressSanitizer; csrc/problem.inc: same rule) */
+                                if (t->lo[j] != t->hi[j] && fabs(xs[j] - rint(xs[j])) > ORC_INTTOL && xs[j] > bv) { bv = xs[j]; branch_j = j; branch_x = xs[j]; }
                             }
                         } else if (pen_mode && !t->P) {
                             /* penalty branching: the fractional binary with the largest product of up / down penalties (first index on
@@ -1666,7 +1680,7 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
                             double bscore = -1.0; int bforced = 0;
                             for (int k = 0; k < nb && !pruned; ++k) {
                                 const int j = bins[k];
-                                if (fabs(xs[j] - rint(xs[j])) <= ORC_INTTOL) continue;
+                                if (fabs(xs[j] - rint(xs[j])) <= ORC_INTTOL || t->lo[j] == t->hi[j]) continue;
                                 const int w = t->where[j];
                                 if (w >= 0) continue;       /* (a fractional binary is basic) */
                                 double pd, pu;
@@ -1696,7 +1710,7 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
                         } else
                         for (int k = 0; k < nb; ++k) {
                             const int j = bins[k];
-                            if (fabs(xs[j] - rint(xs[j])) > ORC_INTTOL) { branch_j = j; branch_x = xs[j]; break; }
+                            if (t->lo[j] != t->hi[j] && fabs(xs[j] - rint(xs[j])) > ORC_INTTOL) { branch_j = j; branch_x = xs[j]; break; }
                         }
                         if (branch_j < 0 && !pruned) {
                             /* leaf: fix every binary at its rounded value, re-solve, verify, restore */
@@ -1736,10 +1750,12 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
                             else set_bounds(t, branch_j, tgt, tgt);
                         }
                         (void)take;
-                        stk_j[depth] = branch_j; stk_first[depth] = take; stk_second[depth] = 1; depth++;
+                        if (depth >= nb) limit = 1;      /* (cannot happen: every level holds a different free binary) */
+                        else { stk_j[depth] = branch_j; stk_first[depth] = take; stk_second[depth] = 1; depth++; }
                         if (!limit && !dive_end) continue; /* evaluate the chosen child */
                     }
                 }
+                if (branch_j >= 0 && depth >= nb) limit = 1;
                 if (branch_j >= 0 && !limit && !finished && !dive_end) {
                     double first = force_first >= 0 ? (double)force_first : (branch_x >= 0.5 ? 1.0 : 0.0);
                     if (have && phase == PH_FINAL && !second_done) first = x_out[branch_j];     /* guided (Danna et al. 2005): towards the incumbent first */
