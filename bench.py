@@ -226,7 +226,7 @@ def cpu_baseline(agents, N_p, N_t, x0, om, midx, n_sample, gap, node_limit, pivo
                                          "incl. pool start-up); value: the first %d of them on one thread" % (len(idx), procs, len(one)))
     except Exception as e:      # noqa: BLE001 -- reported, not fatal: the baseline above stands on its own
         third = dict(solver="scipy.optimize.milp (HiGHS)", error=str(e)[:200])
-    opts = dict(gap_rel=gap, max_nodes=node_limit, presolve=0, max_pivots=pivot_limit)
+    opts = dict(gap_rel=gap, max_nodes=node_limit, presolve=4, max_pivots=pivot_limit)      # (presolve bit 2: the per-instance presolve the kernel runs -- the port restates the SAME algorithm)
     n1 = min(32, len(idx))
     progress("cpu baseline: the C oracle on %d instances (1 thread, then OpenMP on %d threads)" % (len(idx), host["usable_cores"]))
     t0 = time.perf_counter()
