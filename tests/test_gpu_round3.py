@@ -65,7 +65,7 @@ def test_steady_state_closed_loop_instances_against_highs_optimum():
     rel = _check_against_optimum(sub, gold["obj"][ok], GAP)
     proven, within = float((out["status"] == 0).mean()), float((rel <= GAP + 1e-9).mean())
     print("steady state: proven %.4f within-gap %.4f worst %.4f" % (proven, within, rel.max()))
-    assert proven >= 0.985 and within >= 0.99           # (measured 0.988 / 0.996 with the per-instance presolve -- solved COLD here; 0.984 / 0.984 before it)
+    assert proven >= 0.99 and within >= 0.995           # (VERDICT r3's bar.  Measured 0.9961 / 1.0000 with the per-instance presolve and RINS keeping any improvement -- solved COLD here; 0.984 / 0.984 before them)
     # the tail: 99 % of the steady-state instances end within 10 % of the optimum.  The rest is where the search is weakest: an
     # instance whose LP bound is blind to a soft-constraint penalty until the last binary of a dive is fixed (fixture instance 245: LP value 0.65 at
     # depth 62 of the dive, 16.7 at depth 63 for both children) can end at the node limit several times above its optimum of 1.25 -- still a feasible,
@@ -73,7 +73,7 @@ def test_steady_state_closed_loop_instances_against_highs_optimum():
     # round 3, 0.13 without the cost perturbation (the outcome of one dive each time) -- the 8x allowance of round 3 is gone, the cap is what no binary since
     # has exceeded by a factor of two.
     assert np.percentile(rel, 99) <= 0.10, np.percentile(rel, 99)
-    assert rel.max() <= 0.05, float(rel.max())          # (measured 0.020 with the presolve)
+    assert rel.max() <= 0.03, float(rel.max())          # (measured 0.0098: every incumbent within the gap of its optimum)
 
 
 def test_mip_start_keeps_the_answer_and_ends_easy_instances_at_the_root():
