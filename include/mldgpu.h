@@ -90,6 +90,7 @@ typedef struct {
                               (A/B of presolve bit2 on the same problem handle),
                               bit13 no anti-stalling cost
                               perturbation in the dual simplex (A/B of round 3's change), bit14 no long-step (bound flipping) ratio test in the root LP (A/B),
+                              bit15 rounding cuts built one at a time by the whole workgroup instead of a wave per cut (A/B of round 4's change),
                               bit17 a MIP start is evaluated lazily (round 3: only when the deepening passes end without an incumbent) instead of before the root LP (A/B). */
     double time_limit;     /* seconds per INSTANCE on the device clock (Gurobi TimeLimit; the reference passes TimeLimit=20 with every solve,
                               examples/residential_mg_with_pv_and_dewhs/micro_grid_control_simulation.py:232, forwarded by
