@@ -308,3 +308,46 @@ def test_round3_fixtures_are_consistent():
             assert r["obj"] + rc >= opt - 1e-6 * abs(opt) and r["lower_bound"] + rc <= opt + 1e-6 * abs(opt), (kind, i)
             if r["status"] == "optimal":
                 assert r["obj"] + rc - opt <= 1e-2 * abs(r["obj"] + rc) + 1e-9, (kind, i)
+
+
+def test_instance_presolve_keeps_the_optimum_and_pays():
+    """round 4 (presolve bit 2; csrc/problem.inc s_presolve runs the same passes): row-activity bound propagation on the instance's own right-hand side.  It cuts
+    off no integer-feasible point -- the proven optimum at gap 0 is the one without it and HiGHS' --, and on the cfg3 shape it halves the row updates"""
+    work = {0: 0.0, 4: 0.0}
+    for s in range(4):
+        sf, q, h = _instance("cfg3", s, batch=4, tight=True)
+        res = {pre: orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], gap_rel=0.0, max_nodes=100000, presolve=pre) for pre in (0, 4)}
+        assert res[0]["status"] == res[4]["status"] == "optimal"
+        assert abs(res[4]["obj"] - res[0]["obj"]) <= 1e-7 * max(1.0, abs(res[0]["obj"])), (s, res[4]["obj"], res[0]["obj"])
+        if s == 0:
+            ref = _highs(sf, q, h)
+            assert abs(res[4]["obj"] - ref) <= 1e-6 * max(1.0, abs(ref))
+        # the point the presolved search returns satisfies the ORIGINAL rows and bounds
+        x = res[4]["x"]
+        assert np.all(sf["G"] @ x - h <= 1e-6 * np.maximum(1.0, np.abs(h)))
+        assert np.all(x >= sf["lb"] - 1e-9) and np.all(x <= sf["ub"] + 1e-9)
+        work[0] += res[0]["work"]; work[4] += res[4]["work"]
+    assert work[4] < 0.8 * work[0], work
+
+
+def test_instance_presolve_detects_contradicting_fixings_without_a_pivot():
+    """delta_0 = [y_0 >= 0] fixed at 0 while the load alone makes y_0 positive (tests/test_gpu_presolve.py runs the same case on the GPU)"""
+    wl = syn.make_workload("cfg3", batch=1)
+    ag = wl["agents"][0]
+    d = ag["dims"]
+    sf = cn.standard_form(tighten_np.tighten(ag["mats"], d, nu_l=d["nu_l"]), ag["atoms"], wl["N_p"], wl["N_tilde"], nu_l=d["nu_l"])
+    om = ag["omega"][0].copy().reshape(wl["N_tilde"], d["nomega"])
+    om[0, d["nomega"] - 1] = 4000.0
+    om = om.ravel()
+    h, q = cn.rhs(sf["evo"], ag["x0"][0], om), cn.lin_cost(sf["cost"], ag["x0"][0], om)
+    lb, ub = sf["lb"].copy(), sf["ub"].copy()
+    j_delta0 = d["nu"]                          # step 0: u (nu), delta (1), z, mu
+    assert sf["is_bin"][j_delta0]
+    lb[j_delta0] = ub[j_delta0] = 0.0
+    with_pre = orc.solve_milp(q, sf["G"], h, lb, ub, sf["is_bin"], max_nodes=1000, presolve=4)
+    without = orc.solve_milp(q, sf["G"], h, lb, ub, sf["is_bin"], max_nodes=1000, presolve=0)
+    assert with_pre["status"] == without["status"] == "infeasible"
+    assert with_pre["pivots"] == 0 and without["pivots"] > 0
+    lb[j_delta0] = ub[j_delta0] = 1.0           # the satisfiable fixing is still solved
+    ok = orc.solve_milp(q, sf["G"], h, lb, ub, sf["is_bin"], max_nodes=20000, presolve=4, gap_rel=1e-4)
+    assert ok["status"] == "optimal"
