@@ -731,7 +731,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE cfg4 shard: %d agents x %d scenarios per GPU (n_h=7, N_p=24: n=575, 200 binaries, m=500), "
-                               "full branch-and-cut MILP, MIPGap=%g, NodeLimit=%d, IterationLimit=%d; every step solves a fresh, independently seeded "
+                               "full branch-and-cut MILP (library defaults: per-model big-M tightening, per-instance presolve, Gomory + c-MIR cuts), MIPGap=%g, NodeLimit=%d, IterationLimit=%d; every step solves a fresh, independently seeded "
                                "scenario set of the same distribution" % (args.agents, args.scenarios, args.mip_gap, args.node_limit, args.pivot_limit),
                    "timed_region": "K x (%smld_select_inputs [D2D copy of the next staged scenario set] + mld_solve_launch / mld_solve_finish [K3 + K5/K6] (+ RCCL gather of "
                                    "(obj, status, step-0 inputs) from device buffers when N > 1)), the steps alternating over %d problem handles on their own HIP "
