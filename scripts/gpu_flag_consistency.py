@@ -11,7 +11,7 @@ ag = wl["agents"][0]; d = ag["dims"]
 m = gpu.GpuModel([ag["mats"]], d)
 cost = host.cost_from_atoms(ag["atoms"], d, wl["N_p"], wl["N_tilde"])
 outs = {}
-for flag in (0, 16, 32, 48):
+for flag in (0, 16, 32, 48, 4096, 32768, 4096 + 32768):      # (4096: no per-instance presolve, 32768: rounding cuts one at a time)
     p = gpu.GpuProblem(m, wl["N_p"], wl["N_tilde"], cost, max_nodes=2000, gap_rel=1e-4, reserved=flag)
     outs[flag] = p.solve(ag["x0"], ag["omega"]); p.close()
 base = outs[48]
