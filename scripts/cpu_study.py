@@ -38,7 +38,7 @@ def _one(i):
     q = cn.lin_cost(sf["cost"], x0, om)
     rc = cn.cost_const(sf["cost"]["const_terms"], x0, om)
     t0 = time.perf_counter()
-    r = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], gap_rel=_G["gap"], max_nodes=_G["nodes"], presolve=0,
+    r = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], gap_rel=_G["gap"], max_nodes=_G["nodes"], presolve=int(os.environ.get("ORC_PRESOLVE", "4")),
                        max_pivots=_G["pivots"], **eval("dict(%s)" % os.environ.get("ORC_KW", "")))
     dt = time.perf_counter() - t0
     st = dict(optimal=0, infeasible=1, node_limit=2, numerical=3, unbounded=4)[r["status"]]

@@ -25,7 +25,7 @@ for i in range(N):
     sf, sf0 = forms[a], raw[a]
     h = cn.rhs(sf['evo'], x0[i], om[i]); q = cn.lin_cost(sf['cost'], x0[i], om[i])
     r0 = cn.cost_const(sf['cost']['const_terms'], x0[i], om[i])
-    ref = orc.solve_milp(q, sf['G'], h, sf['lb'], sf['ub'], sf['is_bin'], gap_rel=1e-2, max_nodes=400, presolve=0, max_pivots=20000)
+    ref = orc.solve_milp(q, sf['G'], h, sf['lb'], sf['ub'], sf['is_bin'], gap_rel=1e-2, max_nodes=400, presolve=4, max_pivots=20000)
     gs = gpu._lib.STATUS_NAMES[int(out['status'][i])]
     agree += gs == ref['status']
     if np.isfinite(out['obj'][i]):

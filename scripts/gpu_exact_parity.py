@@ -12,7 +12,7 @@ for name, nb in (("cfg2", 48), ("cfg1", 16)):
     for s in range(nb):
         h = cn.rhs(sf["evo"], ag["x0"][s], ag["omega"][s]); q = cn.lin_cost(sf["cost"], ag["x0"][s], ag["omega"][s])
         r0 = cn.cost_const(sf["cost"]["const_terms"], ag["x0"][s], ag["omega"][s])
-        ref = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], max_nodes=20000, presolve=0)
+        ref = orc.solve_milp(q, sf["G"], h, sf["lb"], sf["ub"], sf["is_bin"], max_nodes=20000, presolve=4)
         if ref["status"] == "optimal" and out["status"][s] == 0:
             both += 1; e = abs(out["obj"][s] - ref["obj"] - r0) / max(1.0, abs(ref["obj"] + r0)); worst = max(worst, e)
             if e > 1e-6: mism.append((s, out["obj"][s], ref["obj"] + r0))
