@@ -34,6 +34,8 @@
 #include <string.h>
 
 #define ORC_BIG 1.0e7
+#define ORC_RESTART_ROWS 150      /* cut rows only the root restart may use (csrc/problem.inc S_RESTART_ROWS) */
+#define ORC_RESTART_GAP 0.03      /* the restart runs when the incumbent is within this relative gap of the proven bound */
 #define ORC_PTOL 1e-8
 #define ORC_PTOL_SKIP 1e-6
 #define ORC_DTOL 1e-9
@@ -253,6 +255,7 @@ void orc_rhs(int m, int nx, int nW, const double *H_x, const double *H_w, const 
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
     int n, m0, m, mcap, ld, ntot;
+    int cut_cap;        /* rows (original + cut) the cut generators may fill right now: m0 + max_cuts in the root cut loop, mcap in the root restart */
     double *D;          /* (mcap+1) x ld ; row mcap = reduced costs d (col n = z0) */
     double *Gx, *hx;    /* scaled original rows + cuts: mcap x n, mcap */
     double *q, *rs, *cs;
@@ -1131,7 +1134,7 @@ static int gmi_round(dict_t *t, int max_cuts)
     int added = 0;
     const int m_start = m;
     for (int f = 0; f < nf; ++f) {
-        if (m_start + added >= t->mcap || added >= max_cuts) break;
+        if (m_start + added >= t->cut_cap || added >= max_cuts) break;
         const int r = fr[f].r;
         const double f0 = t->xB[r] - floor(t->xB[r]);
         const double *row = t->D + (size_t)r * ld;
@@ -1272,7 +1275,7 @@ static int mir_round(dict_t *t, int max_cuts)
     int added = 0;
     const int m_start = m;
     for (int q = 0; q < nc; ++q) {
-        if (m_start + added >= t->mcap || added >= max_cuts) break;
+        if (m_start + added >= t->cut_cap || added >= max_cuts) break;
         double bx, nrm2;
         if (mir_build(t, cand[q].row, cand[q].delta, x, ax, &bx, &nrm2) <= 1e-6) continue;
         double nrm = 0;
@@ -1426,7 +1429,7 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
     int status = ORC_INFEASIBLE;
     if ((o->presolve & 1) && !propagate_bounds(G, h, m, n, lb, ub, is_bin)) { st->status = status; free(lb); free(ub); return status; }
     dict_t T; dict_t *t = &T; memset(t, 0, sizeof(T));
-    t->n = n; t->m0 = m; t->m = m; t->mcap = m + o->max_cuts; t->ld = n + 1; t->ntot = n + t->mcap;
+    t->n = n; t->m0 = m; t->m = m; t->mcap = m + o->max_cuts + ((o->max_cuts > 0 && o->cut_rounds > 0) ? ORC_RESTART_ROWS : 0); t->cut_cap = m + o->max_cuts; t->ld = n + 1; t->ntot = n + t->mcap;
     t->max_pivots = o->max_pivots > 0 ? o->max_pivots : 2000000000L;
     t->D = dalloc((size_t)(t->mcap + 1) * t->ld);
     t->Gx = dalloc((size_t)t->mcap * n); t->hx = dalloc(t->mcap);
@@ -1589,6 +1592,7 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
         double *stk_obj = dalloc(nb + 2), *stk_x = dalloc(nb + 2);
         int fresh_child = 0;          /* the node about to be evaluated is the child just created on top of the stack */
         double lbg = root_bound;      /* proven global lower bound: raised by every exhaustive pass */
+        double restart_best = INFINITY;      /* incumbent value of the last root restart */
         status = ORC_NODE_LIMIT;
         for (;;) {
             const double work_at_pass = t->work; const int phase_at_pass = phase;
@@ -1597,6 +1601,35 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
             int finished = 0, dive_end = 0;
             const double best_at_start = best;
             pass++;
+            if (phase == PH_FINAL && have && !rescue && !t->P && o->cut_rounds > 0 && t->mcap > m + o->max_cuts && best < restart_best &&
+                best - lbg <= ORC_RESTART_GAP * fabs(best) && !getenv("ORC_NO_RESTART")) {
+                /* Root restart (round 4; csrc/problem.inc: same rule).  The final search is about to start from the root with an incumbent that is close to the proven
+                 * bound but not within the gap -- under the flat mid-day tariff that is the whole unproven tail.  More cut rounds at the root, under the incumbent's
+                 * cutoff and in the ORC_RESTART_ROWS rows reserved for this, move the bound the last percent for most of them (256 flat-tariff bench instances:
+                 * 3 -> 0 unproven, -4 % row updates; instances that never get here are untouched). */
+                restart_best = best;
+                const double rcut = best - gtol(o, best) + 1e-12;
+                t->cut_cap = t->mcap;
+                int lpr = dual_simplex(t, rcut), stalled = 0;
+                for (int rnd = 0; rnd < o->cut_rounds && lpr == LP_OPTIMAL && t->m < t->mcap; ++rnd) {
+                    const double before = objective(t);
+                    int k = gmi_round(t, o->cuts_per_round);
+                    if (o->mir_per_round > 0) k += mir_round(t, o->mir_per_round);
+                    if (!k) break;
+                    st->cuts += k;
+                    const long saved_cap = t->max_pivots, cap = t->pivots + 4L * m + 200;
+                    t->max_pivots = cap < saved_cap ? cap : saved_cap;
+                    lpr = dual_simplex(t, rcut);
+                    t->max_pivots = saved_cap;
+                    if (lpr != LP_OPTIMAL) break;
+                    if (objective(t) - before < 1e-6 * fmax(1.0, fabs(before))) { if (++stalled >= 3) break; } else stalled = 0;
+                }
+                if (lpr == LP_CUTOFF) { lbg = fmax(lbg, best - gtol(o, best)); status = ORC_OPTIMAL; break; }      /* the root is closed by its bound under the cutoff */
+                if (lpr == LP_OPTIMAL) {
+                    for (int i = m; i < t->m; ++i) if (t->basic[i] == n + i && t->xB[i] > ORC_PURGE_SLACK) t->skip[i] |= 2;
+                    if (objective(t) > lbg) lbg = objective(t);
+                }
+            }
             if (phase == PH_RINS) {   /* fix the binaries on which incumbent and root relaxation agree */
                 nfix = 0;
                 for (int k = 0; k < nb; ++k) {
