@@ -34,8 +34,9 @@
 #include <string.h>
 
 #define ORC_BIG 1.0e7
-#define ORC_RESTART_ROWS 150      /* cut rows only the root restart may use (csrc/problem.inc S_RESTART_ROWS) */
-#define ORC_RESTART_GAP 0.03      /* the restart runs when the incumbent is within this relative gap of the proven bound */
+#define ORC_RESTART_ROWS 0        /* cut rows only the root restart may use (csrc/problem.inc S_RESTART_ROWS: 0 -- the restart takes what the root cut loop left) */
+#define ORC_RESTART_ROUNDS 5       /* cut rounds of a root restart */
+#define ORC_RESTART_GAPS 3.0      /* the restart runs when the incumbent is within this many gap tolerances of the proven bound (MIPGap 1e-2: 3 %) ... */
 #define ORC_PTOL 1e-8
 #define ORC_PTOL_SKIP 1e-6
 #define ORC_DTOL 1e-9
@@ -1601,17 +1602,17 @@ static int solve_core(int n, int m, const double *Pq, const double *q, const dou
             int finished = 0, dive_end = 0;
             const double best_at_start = best;
             pass++;
-            if (phase == PH_FINAL && have && !rescue && !t->P && o->cut_rounds > 0 && t->mcap > m + o->max_cuts && best < restart_best &&
-                best - lbg <= ORC_RESTART_GAP * fabs(best) && !getenv("ORC_NO_RESTART")) {
+            if (phase == PH_FINAL && have && !x_start && !rescue && !t->P && o->cut_rounds > 0 && t->m < t->mcap && best < restart_best &&
+                best - lbg <= ORC_RESTART_GAPS * gtol(o, best) && nodes >= o->max_nodes / 8 && !getenv("ORC_NO_RESTART")) {
                 /* Root restart (round 4; csrc/problem.inc: same rule).  The final search is about to start from the root with an incumbent that is close to the proven
                  * bound but not within the gap -- under the flat mid-day tariff that is the whole unproven tail.  More cut rounds at the root, under the incumbent's
-                 * cutoff and in the ORC_RESTART_ROWS rows reserved for this, move the bound the last percent for most of them (256 flat-tariff bench instances:
-                 * 3 -> 0 unproven, -4 % row updates; instances that never get here are untouched). */
+                 * cutoff and in the cut rows the root cut loop left free, move the bound the last percent for most of them (256 flat-tariff bench instances:
+                 * 3 -> 1 unproven, -3 % row updates; instances that never get here are untouched). */
                 restart_best = best;
                 const double rcut = best - gtol(o, best) + 1e-12;
                 t->cut_cap = t->mcap;
                 int lpr = dual_simplex(t, rcut), stalled = 0;
-                for (int rnd = 0; rnd < o->cut_rounds && lpr == LP_OPTIMAL && t->m < t->mcap; ++rnd) {
+                for (int rnd = 0; rnd < ORC_RESTART_ROUNDS && rnd < o->cut_rounds && lpr == LP_OPTIMAL && t->m < t->mcap; ++rnd) {
                     const double before = objective(t);
                     int k = gmi_round(t, o->cuts_per_round);
                     if (o->mir_per_round > 0) k += mir_round(t, o->mir_per_round);
