@@ -67,8 +67,7 @@ typedef struct {
     int32_t max_pivots;    /* per instance simplex iteration limit (default 50000) */
     int32_t cut_rounds;    /* cut rounds at the root (default -1 = max(10, min(30, binaries / 40)); 0 = no cuts) */
     int32_t cuts_per_round;/* Gomory cuts per round (default -1 = max(80, binaries / 5)) */
-    int32_t max_cuts;      /* rows reserved for the cuts of the root cut loop (default -1 = max(300, rows / 4) up to 400 binaries, rows / 2 above; 0 = no cuts);
-                              150 more rows are reserved for the root restart */
+    int32_t max_cuts;      /* rows reserved for cuts (default -1 = max(300, rows / 4) up to 400 binaries, rows / 2 above; 0 = no cuts) */
     int32_t presolve;      /* default 6.  bit1: per-model probing-based big-M tightening (once, when the problem is created).  bit2 (round 4): per-INSTANCE
                               presolve before the root LP -- row-activity bound propagation with integer rounding on the instance's own right-hand side
                               (its x0 / omega); binaries it fixes are fixed, the implied bounds of the continuous variables are used by the rounding cuts
@@ -92,7 +91,7 @@ typedef struct {
                               bit13 no anti-stalling cost
                               perturbation in the dual simplex (A/B of round 3's change), bit14 no long-step (bound flipping) ratio test in the root LP (A/B),
                               bit15 rounding cuts built one at a time by the whole workgroup instead of a wave per cut (A/B of round 4's change),
-                              bit16 no root restart (more cut rounds at the root once an incumbent leaves a gap of at most 3 %; A/B of round 4's change),
+                              bit16 no root restart (more cut rounds at the root of a cold instance once an incumbent leaves a gap of at most three tolerances; A/B of round 4's change),
                               bit17 a MIP start is evaluated lazily (round 3: only when the deepening passes end without an incumbent) instead of before the root LP (A/B). */
     double time_limit;     /* seconds per INSTANCE on the device clock (Gurobi TimeLimit; the reference passes TimeLimit=20 with every solve,
                               examples/residential_mg_with_pv_and_dewhs/micro_grid_control_simulation.py:232, forwarded by
